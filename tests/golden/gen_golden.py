@@ -1,0 +1,465 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the *reference* tinycarlo (read-only at /root/reference)
+in the build container and writes small input/output fixtures next to this file.
+
+This script is test infrastructure.  It is the only place that imports the reference and
+it never runs on the GPU box (the reference does not travel).  Only the resulting
+.npz/.json data files are consumed by tests/.
+
+Import recipe:
+  * `tinycarlo/__init__.py` needs gymnasium (absent) -> register a bare package object so the
+    sub-modules helper/layer/map/car/camera/renderer import as they are;
+  * `cv2` (absent) -> a shim with `Rodrigues` (closed form) and a *recording* `polylines`.
+    Consequently the int32 segment lists handed to cv2.polylines are pinned, the pixels
+    OpenCV would paint are NOT (raster parity is "unpinned").
+
+Actions are float32-valued but handed to the reference as float64 arrays (the way
+examples/stanley_control.py hands python floats): with NumPy>=2 a float32 action array
+drags Car.velocity/position/rotation down to float32 through NEP-50 weak promotion, which
+is a NumPy-version artefact, not tinycarlo semantics.  float64 inputs give the same
+float64 arithmetic under every NumPy version.
+
+Usage:  python tests/golden/gen_golden.py            (writes into tests/golden/)
+"""
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import yaml
+
+REF = os.environ.get("TINYCARLO_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# ----------------------------------------------------------------------------- shims
+pkg = types.ModuleType("tinycarlo")
+pkg.__path__ = [os.path.join(REF, "tinycarlo")]
+sys.modules["tinycarlo"] = pkg
+
+cv2 = types.ModuleType("cv2")
+_REC = []          # recorded polylines calls of the current capture
+
+
+def _rodrigues(rvec):
+    r = np.asarray(rvec, dtype=np.float64).reshape(3)
+    theta = math.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2])
+    if theta < np.finfo(np.float64).eps:
+        return np.eye(3), None
+    c, s = math.cos(theta), math.sin(theta)
+    c1 = 1.0 - c
+    k = r * (1.0 / theta)
+    rrt = np.outer(k, k)
+    r_x = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return c * np.eye(3) + c1 * rrt + s * r_x, None
+
+
+def _polylines(img, pts, is_closed, color, thickness=1, *a, **k):
+    assert is_closed is False
+    pts = np.asarray(pts)
+    assert pts.dtype == np.int32 and pts.shape == (1, 2, 2), (pts.dtype, pts.shape)
+    _REC.append((img.ndim, pts[0].copy(), color, thickness))
+    return img
+
+
+cv2.Rodrigues = _rodrigues
+cv2.polylines = _polylines
+sys.modules["cv2"] = cv2
+
+from tinycarlo.map import Map            # noqa: E402
+from tinycarlo.car import Car            # noqa: E402
+from tinycarlo.camera import Camera      # noqa: E402
+from tinycarlo.renderer import Renderer  # noqa: E402
+from tinycarlo.layer import Layer        # noqa: E402
+from tinycarlo.helper import clip_angle  # noqa: E402
+
+MAPS = {
+    "simple_layout": "config_simple_layout.yaml",
+    "knuffingen": "config_knuffingen.yaml",
+}
+RESOLUTIONS = {"r64": [64, 64], "r128": [128, 128], "r480": [480, 640]}
+
+
+def load(map_name):
+    path = os.path.join(REF, "examples", MAPS[map_name])
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    m = Map(cfg["map"], base_path=path)
+    car = Car(1 / cfg["sim"].get("fps", 30), m, cfg["car"])
+    ren = Renderer.__new__(Renderer)
+    cams = {}
+    for key, res in RESOLUTIONS.items():
+        cc = dict(cfg["camera"])
+        cc["resolution"] = list(res)
+        cams[key] = Camera(m, car, ren, cc)
+    return cfg, m, car, cams
+
+
+def capture_segments(cam):
+    """Runs Camera.capture_frame('classes') and returns [(layer, x0,y0,x1,y1)] int32 rows in
+    the order cv2.polylines was called for the class planes (camera.py:52-110, renderer.py:46-51)."""
+    _REC.clear()
+    cam.capture_frame("classes")
+    n_layers = len(cam.map.lanelines)
+    rgb = [r for r in _REC if r[0] == 3]
+    cls = [r for r in _REC if r[0] == 2]
+    assert len(rgb) == len(cls)
+    # the class pass carries no layer id: recover it from the rgb pass (same order, colours per layer)
+    colors = cam.map.get_laneline_colors()
+    rows = []
+    li = 0
+    # rgb pass iterates layers in order; colours may repeat between layers, so walk by polylines
+    per_layer = [len(p) for p in cam._last_polylines]
+    k = 0
+    for li in range(n_layers):
+        for _ in range(per_layer[li]):
+            nd, pts, col, th = cls[k]
+            assert list(rgb[k][2]) == list(colors[li])
+            assert np.array_equal(rgb[k][1], pts)
+            rows.append((li, pts[0, 0], pts[0, 1], pts[1, 0], pts[1, 1]))
+            k += 1
+    assert k == len(cls)
+    return np.array(rows, dtype=np.int32).reshape(-1, 5)
+
+
+# capture the per-layer polyline lists the camera hands to the renderer (float endpoints)
+_orig_rgb = Renderer.render_camera_frame_rgb
+
+
+def _spy_rgb(self, points, colors, resolution, line_thickness):
+    _spy_rgb.cam._last_polylines = points
+    return _orig_rgb(self, points, colors, resolution, line_thickness)
+
+
+Renderer.render_camera_frame_rgb = _spy_rgb
+
+
+def capture(cam):
+    _spy_rgb.cam = cam
+    segs = capture_segments(cam)
+    fl = []
+    for li, layer in enumerate(cam._last_polylines):
+        for (a, b) in layer:
+            fl.append((a[0], a[1], b[0], b[1]))
+    return segs, np.array(fl, dtype=np.float64).reshape(-1, 4)
+
+
+def nearest_edge_ids(m, pos):
+    ids = []
+    for layer in m.lanelines:
+        e = layer.get_nearest_edge(pos)
+        ids.append(layer.edges.index(e))
+    return ids
+
+
+def state_vec(car):
+    lp = np.full((4, 2), -1, dtype=np.int32)
+    for i, e in enumerate(car.local_path):
+        lp[i] = (int(e[0]), int(e[1]))
+    return dict(x=float(car.position[0]), y=float(car.position[1]), theta=float(car.rotation),
+                velocity=float(car.velocity), steering=float(car.steering_angle), radius=float(car.radius),
+                front_x=float(car.position_front[0]), front_y=float(car.position_front[1]),
+                lp=lp, lp_len=len(car.local_path), last_maneuver=int(car.last_maneuver))
+
+
+def info_vec(m, car):
+    cte, he, dist, lpc, vel = car.get_info()
+    names = m.get_laneline_names()
+    d = np.array([float(dist[n]) for n in names], dtype=np.float64)
+    c = np.zeros((4, 2), dtype=np.float64)
+    for i, p in enumerate(lpc):
+        c[i] = p
+    return float(cte), float(he), d, c, len(lpc), float(vel)
+
+
+def clip_action(v, s):
+    low = -np.ones(2, dtype=np.float32)
+    high = np.ones(2, dtype=np.float32)
+    cc = np.clip(np.array([v, s], dtype=np.float64), low, high)  # env.py:118 with float64 input
+    assert cc.dtype == np.float64
+    return cc
+
+
+class Rec:
+    def __init__(self):
+        self.d = {}
+
+    def add(self, **kw):
+        for k, v in kw.items():
+            self.d.setdefault(k, []).append(v)
+
+    def arrays(self):
+        return {k: np.array(v) for k, v in self.d.items()}
+
+
+def ragged(lists, width, dtype):
+    off = np.zeros(len(lists) + 1, dtype=np.int64)
+    for i, l in enumerate(lists):
+        off[i + 1] = off[i] + len(l)
+    flat = np.concatenate([np.asarray(l, dtype=dtype).reshape(-1, width) for l in lists]) if lists else np.zeros((0, width), dtype)
+    return flat, off
+
+
+def rollout(map_name, seed, steps, policy, cam_keys, man_period):
+    cfg, m, car, cams = load(map_name)
+    tw = car.track_width
+    rng_env = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))   # gymnasium np_random(seed)
+    rng_act = np.random.default_rng(1000 + seed)
+    rec = Rec()
+    seg_i = {k: [] for k in cam_keys}
+    seg_f = {k: [] for k in cam_keys}
+    rseg_i = {k: [] for k in cam_keys}
+    rseg_f = {k: [] for k in cam_keys}
+    resets = Rec()
+
+    def do_reset(t):
+        car.reset(rng_env)
+        st = state_vec(car)
+        resets.add(step=t, spawn_node=int(car.local_path[0][0]), **{k: v for k, v in st.items()})
+        for k in cam_keys:
+            si, sf = capture(cams[k])
+            rseg_i[k].append(si)
+            rseg_f[k].append(sf)
+        assert car.get_info()[0] == 0 and car.get_info()[3] == []
+
+    do_reset(0)
+    man = 0
+    info = None
+    for t in range(steps):
+        if t % man_period == 0:
+            man = int(rng_act.integers(0, 4))
+        if policy == "random":
+            v = float(np.float32(rng_act.uniform(0.3, 1.0)))
+            s = float(np.float32(rng_act.uniform(-1.0, 1.0)))
+        elif policy == "wild":       # out-of-range + negative velocities: exercises the action clip and reverse look-ahead
+            v = float(np.float32(rng_act.uniform(-1.5, 1.5)))
+            s = float(np.float32(rng_act.uniform(-1.5, 1.5)))
+        else:  # stanley lateral controller (examples/stanley_control.py:52-55) with a little noise
+            speed = 0.6
+            if info is None:
+                cte_, he_ = 0.0, 0.0
+            else:
+                cte_, he_ = info[0], info[1]
+            sc = math.atan2(4 * cte_, speed)
+            s = (he_ + sc) * 180 / math.pi / car.max_steering_angle + rng_act.normal(0, 0.05)
+            v = float(np.float32(speed))
+            s = float(np.float32(s))
+        pre = state_vec(car)
+        cc = clip_action(v, s)
+        exc = False
+        try:
+            trunc = car.step(cc[0], cc[1], man)
+        except TypeError:
+            # U-turn with no edge inside the +-30 deg margin: reference raises at car.py:143
+            exc = True
+            trunc = True
+        post = state_vec(car) if not exc else None
+        if exc:
+            # car.local_path == [None]; nothing downstream is defined.  Record and reset.
+            rec.add(exception=True)
+            raise RuntimeError("U-turn exception hit in rollout; handle it")
+        for k in cam_keys:
+            si, sf = capture(cams[k])
+            seg_i[k].append(si)
+            seg_f[k].append(sf)
+        cte, he, dist, lpc, nlpc, vel = info_vec(m, car)
+        info = (cte, he)
+        reward = max((-1 / tw) * cte + 1, 0)          # env.py:93
+        terminated = bool(cte > tw * 10)              # env.py:99
+        ne = nearest_edge_ids(m, car.position)
+        rec.add(v=v, s=s, maneuver=man, truncated=bool(trunc), cte=cte, heading_error=he, dist=dist,
+                lp_coords=lpc, n_lp_coords=nlpc, info_velocity=vel, reward=float(reward), terminated=terminated,
+                nearest_edge=np.array(ne, dtype=np.int32),
+                **{"pre_" + k: v_ for k, v_ in pre.items()}, **{"post_" + k: v_ for k, v_ in post.items()})
+        if terminated or trunc:
+            do_reset(t + 1)
+            info = None
+    out = rec.arrays()
+    for k, v_ in resets.arrays().items():
+        out["reset_" + k] = v_
+    for k in cam_keys:
+        out[f"seg_{k}"], out[f"seg_{k}_off"] = ragged(seg_i[k], 5, np.int32)
+        out[f"segf_{k}"], _ = ragged(seg_f[k], 4, np.float64)
+        out[f"rseg_{k}"], out[f"rseg_{k}_off"] = ragged(rseg_i[k], 5, np.int32)
+        out[f"rsegf_{k}"], _ = ragged(rseg_f[k], 4, np.float64)
+    out["seed"] = seed
+    return out
+
+
+def single_steps(map_name, n, seed):
+    """Independent (state, action) -> state' pairs spread over the lanepath (teacher-forced K1/K2/K3/G*)."""
+    cfg, m, car, cams = load(map_name)
+    rng = np.random.default_rng(seed)
+    lp = m.lanepath
+    rec = Rec()
+    n_exc = 0
+    while len(rec.d.get("v", [])) < n:
+        e = lp.edges[int(rng.integers(0, len(lp.edges)))]
+        n0, n1 = lp.nodes[e[0]], lp.nodes[e[1]]
+        a = rng.uniform(-0.3, 1.3)
+        ori = math.atan2(n1[1] - n0[1], n1[0] - n0[0])
+        px = n0[0] + a * (n1[0] - n0[0]) + rng.normal(0, 0.03)
+        py = n0[1] + a * (n1[1] - n0[1]) + rng.normal(0, 0.03)
+        th = clip_angle(ori + rng.normal(0, 0.5) + (math.pi if rng.random() < 0.1 else 0.0))
+        car.position = [px - car.wheelbase * math.cos(th), py - car.wheelbase * math.sin(th)]
+        car.rotation = th
+        car.update_position_front()
+        car.velocity = float(rng.uniform(-0.05, 0.15))
+        car.steering_angle = float(rng.uniform(-30, 30)) if rng.random() < 0.9 else 0.0
+        car.radius = 0.0
+        car.local_path = [(int(e[0]), int(e[1]))]
+        car.last_maneuver = int(rng.integers(0, 4))
+        man = int(rng.integers(0, 4))
+        v = float(np.float32(rng.uniform(-1.2, 1.2)))
+        s = float(np.float32(rng.uniform(-1.2, 1.2))) if rng.random() < 0.9 else float(np.float32(car.steering_angle / car.max_steering_angle))
+        pre = state_vec(car)
+        cc = clip_action(v, s)
+        try:
+            trunc = car.step(cc[0], cc[1], man)
+        except TypeError:
+            n_exc += 1
+            rec_exc.add(v=v, s=s, maneuver=man, **{"pre_" + k: v_ for k, v_ in pre.items()})
+            continue
+        post = state_vec(car)
+        cte, he, dist, lpc, nlpc, vel = info_vec(m, car)
+        ne = nearest_edge_ids(m, car.position)
+        rec.add(v=v, s=s, maneuver=man, truncated=bool(trunc), cte=cte, heading_error=he, dist=dist,
+                lp_coords=lpc, n_lp_coords=nlpc, nearest_edge=np.array(ne, dtype=np.int32),
+                **{"pre_" + k: v_ for k, v_ in pre.items()}, **{"post_" + k: v_ for k, v_ in post.items()})
+    out = rec.arrays()
+    for k, v_ in rec_exc.arrays().items():
+        out["exc_" + k] = v_
+    rec_exc.d.clear()
+    return out
+
+
+rec_exc = Rec()
+
+
+def unit_vectors():
+    """Known-answer vectors of the reference's own unit tests (test/test_layer.py, test/test_helper.py):
+    inputs transcribed as data, outputs computed by the reference and checked against the
+    expectations stated in those tests."""
+    out = {"clip_angle": [], "nearest_edge": [], "nearest_node": [], "nearest_edge_orient": [],
+           "within_bounds": [], "distance_to_edge": []}
+    pi = math.pi
+    for a, exp in [(0, 0), (pi, pi), (-pi, -pi), (2 * pi, 0), (-2 * pi, 0), (3 * pi, pi), (-3 * pi, -pi),
+                   (-3 / 2 * pi, pi / 2), (3 / 2 * pi, -pi / 2)]:
+        r = clip_angle(a)
+        assert r == exp
+        out["clip_angle"].append({"in": a, "out": r})
+
+    def L(n, e):
+        return Layer("test", (0, 0, 0), n, e)
+
+    def ne_case(n, e, cases):
+        layer = L(n, e)
+        for p, exp in cases:
+            r = layer.get_nearest_edge(p)
+            assert r == e[exp]
+            out["nearest_edge"].append({"nodes": n, "edges": e, "p": p, "edge_idx": exp})
+
+    ne_case([(0, 0), (4, 0), (0, 4), (4, 4)], [(0, 1), (2, 3)],
+            [((0, 1), 0), ((4, 1), 0), ((1, 0), 0), ((1, 4), 1), ((1, 5), 1), ((0, -1), 0), ((-1, 0), 0), ((-1, -1), 0),
+             ((-1, 5), 1), ((0, 2.01), 1), ((0, 1.99), 0), ((2, 2.01), 1), ((2, 1.99), 0), ((2, 2), 0)])
+    ne_case([(0, 0), (3, 0), (3, 3)], [(0, 1), (1, 2)],
+            [((0, 3), 0), ((1, 1), 0), ((1, 2), 0), ((1, 3), 1), ((1, 4), 1), ((2, 1), 0), ((2, 2), 1), ((4, 0), 1), ((3, -1), 0)])
+
+    n = [(0, 0), (4, 0), (0, 4), (4, 4)]
+    layer = L(n, [])
+    for p, exp in [((0, 1), 0), ((4, 1), 1), ((1, 0), 0), ((1, 4), 2), ((1, 5), 2), ((0, -1), 0), ((-1, 0), 0), ((-1, -1), 0),
+                   ((-1, 5), 2), ((0, 2.01), 2), ((0, 1.99), 0), ((2.1, 2.1), 3), ((2.1, 1.99), 1), ((1.99, 1.99), 0),
+                   ((1.99, 2.1), 2), ((2, 2), 0)]:
+        assert layer.get_nearest_node(p) == exp
+        out["nearest_node"].append({"nodes": n, "p": p, "node_idx": exp})
+
+    def neo_case(n, e, cases):
+        layer = L(n, e)
+        for p, o, exp in cases:
+            r = layer.get_nearest_edge_with_orientation(p, o)
+            assert r == (None if exp is None else e[exp])
+            out["nearest_edge_orient"].append({"nodes": n, "edges": e, "p": p, "orientation": o, "edge_idx": -1 if exp is None else exp})
+
+    rad = math.radians
+    neo_case([(0, 0), (3, 0)], [(0, 1), (1, 0)],
+             [((0, 0), 0, 0), ((0, 0), pi, 1), ((0, 0), -pi, 1), ((0, 0), rad(29), 0), ((0, 0), rad(-29), 0),
+              ((0, 0), rad(180 - 29), 1), ((0, 0), rad(-180 + 29), 1)])
+    neo_case([(0, 0), (3, 0), (3, 3)], [(0, 1), (1, 2)],
+             [((0, 3), 0, 0), ((3, 3), 0, 0), ((3, 3), rad(30), 0), ((3, 3), rad(45), None), ((3, 3), rad(60.01), 1),
+              ((0, 0), rad(90), 1), ((0, 0), pi, None), ((0, 0), -pi, None)])
+
+    def wb_case(n, e, cases):
+        layer = L(n, e)
+        for p, exp in cases:
+            assert layer.is_position_within_edge_bounds(p, e[0]) == exp
+            out["within_bounds"].append({"nodes": n, "edges": e, "p": p, "within": exp})
+
+    wb_case([(0, 0), (3, 0)], [(0, 1)], [((0, 5), True), ((-1, 5), False), ((3.1, 5), False), ((3, 5), True), ((1, -5), True),
+                                         ((1, 0), True), ((1, 0.1), True), ((0, 0), True), ((3, 0), True), ((3.001, 0), False)])
+    wb_case([(0, 0), (3, 0)], [(1, 0)], [((0, 5), True), ((-1, 5), False), ((3.1, 5), False), ((3, 5), True), ((1, -5), True),
+                                         ((1, 0), True), ((1, 0.1), True)])
+    wb_case([(0, 0), (0, 3)], [(0, 1)], [((5, 0), True), ((5, 1), True), ((5, 3), True), ((5, 4), False), ((-5, 0), True),
+                                         ((-5, 1), True), ((-5, -0.1), False), ((0, 0), True), ((0, 3), True)])
+    wb_case([(0, 0), (3, 3)], [(0, 1)], [((0, 3), True), ((3, 0), True), ((3, 3), True), ((0, 0), True), ((1, 1), True),
+                                         ((-1, -1), False), ((4, 4), False)])
+
+    def de_case(n, e, cases, tol=0.0):
+        layer = L(n, e)
+        for p, exp in cases:
+            r = layer.distance_to_edge(p, e[0])
+            assert abs(r - exp) <= tol
+            out["distance_to_edge"].append({"nodes": n, "edges": e, "p": p, "distance": r, "expected": exp, "tol": tol})
+
+    de_case([(0, 0), (3, 0)], [(0, 1)], [((0, 0), 0), ((2, 1), -1), ((5, 2), -2), ((5, -2), 2), ((-5, -2), 2)])
+    de_case([(0, 0), (3, 0)], [(1, 0)], [((0, 0), 0), ((2, 1), 1), ((5, 2), 2), ((5, -2), -2), ((-5, -2), -2)])
+    de_case([(0, 0), (0, 3)], [(0, 1)], [((0, 0), 0), ((1, 2), 1), ((2, 5), 2), ((-2, 5), -2), ((-2, -5), -2)])
+    de_case([(0, 0), (0, 3)], [(1, 0)], [((0, 0), 0), ((1, 2), -1), ((2, 5), -2), ((-2, 5), 2), ((-2, -5), 2)])
+    h = math.sqrt(18) / 2
+    de_case([(0, 0), (3, 3)], [(0, 1)], [((0, 3), -h), ((3, 0), h)], 1e-5)
+    de_case([(0, 0), (3, 3)], [(1, 0)], [((0, 3), h), ((3, 0), -h)], 1e-5)
+    de_case([(0, 3), (3, 0)], [(0, 1)], [((0, 0), h), ((3, 3), -h)], 1e-5)
+    de_case([(0, 3), (3, 0)], [(1, 0)], [((0, 0), -h), ((3, 3), h)], 1e-5)
+    return out
+
+
+def camera_mats():
+    out = {}
+    for mn in MAPS:
+        cfg, m, car, cams = load(mn)
+        for k, cam in cams.items():
+            out[f"{mn}_{k}"] = {"E": cam.E.tolist(), "K": cam.K.tolist(), "resolution": cam.resolution,
+                                "position": list(cam.position), "orientation": list(cam.orientation), "fov": cam.fov}
+    return out
+
+
+def main():
+    with open(os.path.join(OUT, "unit_vectors.json"), "w") as f:
+        json.dump(unit_vectors(), f)
+    with open(os.path.join(OUT, "camera_mats.json"), "w") as f:
+        json.dump(camera_mats(), f)
+    jobs = [
+        # (map, seed, steps, policy, camera keys, maneuver period)
+        ("simple_layout", 0, 400, "random", ["r64"], 64),
+        ("simple_layout", 1, 400, "stanley", ["r64", "r128"], 16),
+        ("simple_layout", 2, 300, "wild", ["r64"], 8),
+        ("simple_layout", 3, 60, "stanley", ["r480"], 16),
+        ("knuffingen", 0, 400, "random", ["r128"], 64),
+        ("knuffingen", 1, 400, "stanley", ["r64", "r128"], 16),
+        ("knuffingen", 2, 300, "wild", ["r128"], 8),
+        ("knuffingen", 3, 60, "stanley", ["r480"], 16),
+    ]
+    for mn, seed, steps, pol, cks, mp in jobs:
+        out = rollout(mn, seed, steps, pol, cks, mp)
+        name = f"rollout_{mn}_{pol}_{seed}.npz"
+        np.savez_compressed(os.path.join(OUT, name), **out)
+        print(name, "resets", len(out["reset_step"]), "trunc", int(out["truncated"].sum()), "term", int(out["terminated"].sum()))
+    for mn in MAPS:
+        out = single_steps(mn, 4000, 7)
+        np.savez_compressed(os.path.join(OUT, f"single_{mn}.npz"), **out)
+        print("single", mn, "n", len(out["v"]), "trunc", int(out["truncated"].sum()),
+              "uturn_exc", len(out.get("exc_v", [])))
+
+
+if __name__ == "__main__":
+    main()
