@@ -1,0 +1,52 @@
+"""Shared helpers for the test-suite: bundled configs -> Map / CarParams / Camera, golden loaders."""
+import copy
+import os
+
+import numpy as np
+import yaml
+
+from tinycarlo_amd.camera import Camera
+from tinycarlo_amd.config import CarParams, bundled_config
+from tinycarlo_amd.map import Map
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RES = {"r64": [64, 64], "r128": [128, 128], "r480": [480, 640]}
+CFG = {"simple_layout": "config_simple_layout.yaml", "knuffingen": "config_knuffingen.yaml"}
+
+_cache = {}
+
+
+def load_cfg(map_name):
+    path = bundled_config(CFG[map_name])
+    with open(path) as f:
+        return yaml.safe_load(f), path
+
+
+def setup(map_name, res_key="r64", **cam_over):
+    """-> (cfg, Map, CarParams, Camera) for a bundled map with the camera resolution overridden."""
+    cfg, path = load_cfg(map_name)
+    key = ("map", map_name)
+    if key not in _cache:
+        _cache[key] = Map(cfg["map"], base_path=path)
+    m = _cache[key]
+    car = CarParams.from_config(1 / cfg["sim"].get("fps", 30), cfg["car"])
+    cc = copy.deepcopy(cfg["camera"])
+    cc["resolution"] = list(RES[res_key])
+    cc.update(cam_over)
+    return cfg, m, car, Camera(cc)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def rollout_files():
+    return sorted(f for f in os.listdir(GOLDEN) if f.startswith("rollout_") and f.endswith(".npz"))
+
+
+def map_of(fname):
+    return "simple_layout" if "simple_layout" in fname else "knuffingen"
+
+
+def cam_keys(d):
+    return [k[4:] for k in d.files if k.startswith("seg_") and not k.endswith("_off")]
