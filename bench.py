@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched tinycarlo step() on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one batched step() of `--envs` envs per GPU (default 4096): ONE launch of the fused HIP
+kernel (kinematics -> lanepath tracking -> lane-line distances -> camera clip/project -> raster
+-> uint8 observation store), inputs (actions) already resident in HBM, observations left in HBM.
+Workloads (BASELINE.json configs):
+    cfg3 (default)  4096 envs, simple_layout, 64x64 'classes', with camera raster      [the metric's config]
+    cfg2            same, no_observation=True (kinematics + tracking + distances only)
+    cfg4            4096 envs/GPU, knuffingen, 128x128 'classes'
+    cfg5            8192 envs, knuffingen, 480x640 'rgb'
+Envs are sharded over ranks with no data-path collective; at N>1 rewards/terminated/truncated of
+every rank are gathered to rank 0 over RCCL each step (staged, asynchronous; `--gather none|flags|obs`).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+B_STATE = 240          # algorithmic state/action/info bytes per env-step
+
+WORKLOADS = {
+    "cfg2": dict(map="simple_layout", res=[64, 64], fmt="classes", envs=4096, no_obs=True),
+    "cfg3": dict(map="simple_layout", res=[64, 64], fmt="classes", envs=4096, no_obs=False),
+    "cfg4": dict(map="knuffingen", res=[128, 128], fmt="classes", envs=4096, no_obs=False),
+    "cfg5": dict(map="knuffingen", res=[480, 640], fmt="rgb", envs=8192, no_obs=False),
+}
+
+
+def make_config(w):
+    import yaml
+    from tinycarlo_amd.config import bundled_config
+    path = bundled_config(f"config_{w['map']}.yaml")
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    cfg["camera"]["resolution"] = list(w["res"])
+    cfg["sim"]["observation_space_format"] = w["fmt"]
+    cfg["map"]["json_path"] = os.path.join(os.path.dirname(path), cfg["map"]["json_path"])
+    return cfg
+
+
+def gen_actions(n_envs, n_steps, seed, device):
+    """v ~ U(0.3,1), s ~ U(-1,1), maneuver ~ U{0..3} resampled every 64 steps, on device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cc = torch.empty((n_steps, n_envs, 2), dtype=torch.float32, device=device)
+    cc[:, :, 0].uniform_(0.3, 1.0, generator=g)
+    cc[:, :, 1].uniform_(-1.0, 1.0, generator=g)
+    nblk = (n_steps + 63) // 64
+    man_blk = torch.randint(0, 4, (nblk, n_envs), dtype=torch.int32, device=device, generator=g)
+    man = man_blk.repeat_interleave(64, dim=0)[:n_steps].contiguous()
+    return cc, man
+
+
+def cpu_baseline(w, cfg, budget_env_steps):
+    """The CPU oracle (oracle/tc_oracle.c, libm mode, OpenMP over envs) timed on this box's host cores on a
+    bounded sample of the same workload: same map / resolution / format / action distribution."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from tinycarlo_amd.camera import Camera
+    from tinycarlo_amd.config import CarParams
+    from tinycarlo_amd.map import Map
+    from tinycarlo_amd import gym
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    m = Map(cfg["map"])
+    car = CarParams.from_config(1 / cfg["sim"].get("fps", 30), cfg["car"])
+    cam = Camera(cfg["camera"])
+    n = min(w["envs"], 1024)
+    steps = max(4, budget_env_steps // n)
+    orc.set_math_mode(orc.MATH_LIBM)
+    o = orc.Oracle(m, car, cam, orc.FMT_CLASSES if w["fmt"] == "classes" else orc.FMT_RGB, n, threads=cores)
+    rngs = [gym.np_random(i)[0] for i in range(n)]
+    o.reset([m.sample_spawn_node(r) for r in rngs], flags=orc.F_NO_OBSERVATION)
+    o.spawn_queue = np.array([[m.sample_spawn_node(r) for _ in range(16)] for r in rngs], dtype=np.int32)
+    rng = np.random.default_rng(0)
+    flags = orc.F_AUTORESET | (orc.F_NO_OBSERVATION if w["no_obs"] else 0)
+    cc = np.stack([rng.uniform(0.3, 1, (steps, n)), rng.uniform(-1, 1, (steps, n))], axis=2)
+    man = rng.integers(0, 4, n).astype(np.int32)
+    o.step(cc[0], man, flags=flags, with_obs=not w["no_obs"])  # warm-up
+    t0 = time.perf_counter()
+    for t in range(steps):
+        o.step(cc[t], man, flags=flags, with_obs=not w["no_obs"])
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {steps} steps of the same workload, oracle/tc_oracle.c (scalar f64, libm) with OpenMP over envs, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the workload's)")
+    ap.add_argument("--gather", default="flags", choices=["none", "flags", "obs"],
+                    help="what is gathered to rank 0 over RCCL each step when --gpus > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=int, default=200000, help="env-steps of the CPU baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+            sys.exit(2)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from tinycarlo_amd.vec_env import TinyCarloVecEnv
+    from tinycarlo_amd.distributed import RankGather
+
+    w = dict(WORKLOADS[args.workload])
+    if args.envs:
+        w["envs"] = args.envs
+    cfg = make_config(w)
+    n = w["envs"]
+    env = TinyCarloVecEnv(cfg, num_envs=n, device=device, autoreset=True, spawn_queue_len=32)
+    env.no_observation = w["no_obs"]
+    env.reset(seed=rank * n)  # env i of rank r is the reference env seeded r*n + i
+    K, W = args.steps, args.warmup
+    period = min(K + W, 1024)  # distinct action batches kept in HBM (reused cyclically beyond that)
+    cc, man = gen_actions(n, period, seed=rank, device=device)
+    gather = RankGather(env, what=args.gather) if world > 1 and args.gather != "none" else None
+
+    def run(k0, k):
+        for t in range(k0, k0 + k):
+            i = t % period
+            env.step_device(cc[i], man[i])
+            if gather is not None:
+                gather.step()
+
+    run(0, W)
+    if gather is not None:
+        gather.wait()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(W, K)
+    ev1.record()
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_resets = int(env._aux["spawn_cursor"].sum().item())
+    C = env.n_classes
+    H, Wd = env.camera.resolution
+    b_obs = 0 if w["no_obs"] else (C * H * Wd if w["fmt"] == "classes" else 3 * H * Wd)
+    bytes_per_env_step = B_STATE + b_obs
+    kernel_s = ev_ms / 1e3 / K  # HIP events on the launch stream around the K timed launches
+    achieved = bytes_per_env_step * n / kernel_s / 1e9
+    out = {
+        "metric": "env-steps/sec (whole node)",
+        "value": world * n * K / dt,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n} envs/GPU, {w['map']} map, {H}x{Wd} '{w['fmt']}' obs, "
+                               + ("kinematics+tracking+distances only (no_observation)" if w["no_obs"] else "with camera laneline raster"),
+                   "envs_per_gpu": n, "actions": "v~U(0.3,1) s~U(-1,1) maneuver~U{0..3}/64 steps, on device",
+                   "autoreset": True, "resets_in_run": n_resets, "gather": args.gather if world > 1 else "n/a",
+                   "lds_bytes_per_env": env.lds_bytes},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "tc_env_kernel", "kernel_us": kernel_s * 1e6,
+                     "algorithmic_bytes_per_launch": bytes_per_env_step * n},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, cfg, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+/* tinycarlo_hip.h -- C ABI of libtinycarlo_hip.so: batched tinycarlo step()/reset() on one MI355X.
+ *
+ * The reference (emrullahArkun/tinycarlo) is pure Python and has no FFI; its only seam is the
+ * gymnasium API of tinycarlo/env.py.  This header is what a Python `TinyCarloEnv` binds through
+ * ctypes to move the per-step hot path onto the GPU (binding shown in INTEGRATION.md):
+ *
+ *   reference interface replaced                                  entry point here
+ *   ------------------------------------------------------------  -------------------------
+ *   Map.__init__ / __change_scale      tinycarlo/map.py:9-37       tc_map_create
+ *   Car.__init__, Camera.__init__      car.py:10-19, camera.py:12-24  tc_env_create
+ *   Camera.update_params               camera.py:48-50             tc_env_set_camera
+ *   TinyCarloEnv.reset                 env.py:101-113              tc_reset
+ *     (Car.reset car.py:34-44, Map.sample_spawn map.py:51-69 with the node index drawn by the host RNG)
+ *   TinyCarloEnv.step                  env.py:115-147              tc_step
+ *     (Car.step car.py:70-125, Car.find_local_path 127-148, Layer.* layer.py:33-187,
+ *      Camera.capture_frame camera.py:52-110, Renderer.render_camera_frame_{rgb,classes}
+ *      renderer.py:36-51, Car.get_info car.py:46-68, default reward/termination env.py:87-99)
+ *
+ * Conventions
+ *   - N independent envs live as structure-of-arrays in device memory OWNED BY THE CALLER
+ *     (e.g. torch tensors); the library stores the pointers given to tc_env_bind and never frees them.
+ *   - every pointer inside tc_buffers, and the action pointers of tc_step / tc_reset, are DEVICE
+ *     pointers on the device that was current at tc_map_create time.
+ *   - kernels are enqueued on the hipStream_t passed as `stream` (void*, NULL = default stream);
+ *     no call synchronises the device except tc_map_create / tc_env_create / tc_*_destroy.
+ *   - one host thread per env handle at a time.
+ *   - every function returns 0 on success or a negative TC_E_* code; nothing throws.
+ *   - arithmetic is IEEE double like the reference (python floats / numpy float64); pixel
+ *     coordinates are int32, observations uint8.
+ */
+#ifndef TINYCARLO_HIP_H
+#define TINYCARLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TC_ABI_VERSION 1
+#define TC_MAX_LAYERS 16
+
+/* error codes */
+#define TC_OK 0
+#define TC_E_INVALID (-1)  /* bad argument / inconsistent sizes */
+#define TC_E_HIP (-2)      /* a HIP runtime call failed (tc_last_error() has the text) */
+#define TC_E_NOMEM (-3)
+#define TC_E_UNBOUND (-4)  /* tc_step/tc_reset before tc_env_bind */
+#define TC_E_LDS (-5)      /* map/camera too large for the 160 KiB LDS budget of one workgroup */
+
+/* observation formats (sim.observation_space_format, env.py:42,67-72) */
+#define TC_FMT_RGB 0     /* uint8 [N][H][W][3] */
+#define TC_FMT_CLASSES 1 /* uint8 [N][C][H][W], values 0/255 */
+
+/* action dtypes for tc_step */
+#define TC_F32 0
+#define TC_F64 1
+
+/* step / reset flags */
+#define TC_F_NO_OBSERVATION 1u /* env.no_observation (env.py:60,78-81): obs left untouched, no camera work */
+#define TC_F_WRAPPED 2u        /* env.wrapped (env.py:56,137-138): reward = 0, terminated = false */
+#define TC_F_AUTORESET 4u      /* envs whose needs_reset flag is set are re-spawned from spawn_queue at the
+                                  start of the step (their action is ignored, reward 0, info empty) and the
+                                  flag is set again from terminated|truncated at the end of the step */
+
+/* per-env status bits (tc_buffers.status), situations where the reference raises a Python exception */
+#define TC_S_UTURN_NO_EDGE 1 /* U-turn found no lanepath edge within +-30 deg (TypeError at car.py:143): truncated */
+#define TC_S_PICK_EMPTY 2    /* neighbour list made only of self-loops (ValueError at layer.py:123): truncated */
+#define TC_S_BAD_SPAWN 4     /* spawn node out of range or without out-edge: first spawnable node used instead */
+#define TC_S_NOT_RESET 8     /* tc_step on an env that was never reset: truncated, state untouched */
+
+typedef struct tc_map tc_map;
+typedef struct tc_env tc_env;
+
+/* Host-side description of a map, coordinates already in metres (map.py:28-37).
+ * Lane-line layers are concatenated in JSON key order (map.py:23); edge node ids are layer-local. */
+typedef struct {
+  int32_t n_layers;
+  const int32_t* node_count; /* [n_layers] */
+  const int32_t* edge_count; /* [n_layers] */
+  const double* nodes;       /* [sum node_count][2] */
+  const int32_t* edges;      /* [sum edge_count][2] */
+  const uint8_t* colors;     /* [n_layers][3], written to channels 0,1,2 as given (renderer.py:43) */
+  int32_t lanepath_node_count;
+  int32_t lanepath_edge_count;
+  const double* lanepath_nodes;  /* [lanepath_node_count][2] */
+  const int32_t* lanepath_edges; /* [lanepath_edge_count][2] */
+} tc_map_desc;
+
+/* car.py:10-19 */
+typedef struct {
+  double T; /* 1/fps, env.py:40-41 */
+  double wheelbase, track_width, max_velocity, max_steering_angle;
+  double steering_speed;                  /* used when has_steering_speed */
+  double max_acceleration, max_deceleration; /* used when has_max_acceleration */
+  int32_t has_steering_speed, has_max_acceleration;
+} tc_car_params;
+
+/* camera.py:12-24; E and K are computed on the host exactly as camera.py:145-178 does */
+typedef struct {
+  int32_t height, width;
+  double E[12]; /* 3x4 row major */
+  double K[9];  /* 3x3 row major */
+  double max_range;
+  int32_t line_thickness;
+  int32_t format; /* TC_FMT_* */
+} tc_camera_params;
+
+/* Device buffers, all [N] unless noted.  State is in/out, the rest is written by tc_step/tc_reset. */
+typedef struct {
+  /* --- car state (car.py:25-32) */
+  double *x, *y, *theta;  /* rear-axle position (m), heading (rad) */
+  double *velocity;       /* m/s */
+  double *steering;       /* deg */
+  double *radius;         /* m, 0 when driving straight */
+  double *front_x, *front_y;
+  int32_t* local_path;    /* [N][8]: up to 4 lanepath edges (n0,n1), -1 padded */
+  int32_t* lp_len;        /* 1 after reset, 1..4 after a step */
+  int32_t* last_maneuver;
+  /* --- per-step outputs (env.py:83-85,136-147) */
+  double *cte, *heading_error, *reward;
+  uint8_t *terminated, *truncated;
+  int32_t* status;             /* TC_S_* bits */
+  double* laneline_distances;  /* [N][n_layers] */
+  int32_t* nearest_edge;       /* [N][n_layers] layer-local edge index of Layer.get_nearest_edge(rear), -1 if info empty */
+  uint8_t* obs;                /* [N][C][H][W] or [N][H][W][3]; may be NULL if every call passes TC_F_NO_OBSERVATION */
+  /* --- auto-reset (TC_F_AUTORESET) */
+  uint8_t* needs_reset;        /* [N] */
+  const int32_t* spawn_queue;  /* [N][spawn_queue_len] spawnable lanepath node ids drawn by the host RNG */
+  int32_t* spawn_cursor;       /* [N] */
+  int32_t spawn_queue_len;
+} tc_buffers;
+
+int tc_abi_version(void);
+const char* tc_last_error(void);
+
+int tc_map_create(const tc_map_desc* desc, tc_map** out);
+int tc_map_destroy(tc_map* map);
+
+int tc_env_create(const tc_map* map, const tc_car_params* car, const tc_camera_params* cam, int32_t num_envs,
+                  tc_env** out);
+int tc_env_destroy(tc_env* env);
+int tc_env_bind(tc_env* env, const tc_buffers* buffers);
+/* New E/K (and range / thickness) for all envs; takes effect for launches enqueued afterwards. */
+int tc_env_set_camera(tc_env* env, const tc_camera_params* cam);
+/* bytes of one env's observation */
+int64_t tc_env_obs_bytes(const tc_env* env);
+/* dynamic LDS bytes one workgroup of the step kernel uses (for occupancy reporting) */
+int64_t tc_env_lds_bytes(const tc_env* env);
+
+/* env.py:101-113 for the envs selected by mask (NULL = all): pose from spawn_nodes[i], zeroed info,
+ * observation rendered unless TC_F_NO_OBSERVATION. */
+int tc_reset(tc_env* env, const int32_t* spawn_nodes, const uint8_t* mask, uint32_t flags, void* stream);
+
+/* env.py:115-147 for all envs.  car_control: [N][2] (velocity, steering in [-1,1], clipped like env.py:118),
+ * dtype TC_F32 or TC_F64; maneuver: [N] in {0,1,2,3}. */
+int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const int32_t* maneuver, uint32_t flags,
+            void* stream);
+
+/* Re-render the observation of the current state without stepping (Camera.capture_frame, camera.py:52). */
+int tc_render(tc_env* env, uint32_t flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYCARLO_HIP_H */

@@ -1,0 +1,250 @@
+"""GPU parity: the HIP path (through the C ABI, via TinyCarloVecEnv) against the CPU oracle and
+against the reference's golden vectors.  Run on the MI355X box with `pytest -m gpu`.
+
+Bars (BASELINE.json north_star):
+  * class-mask / rgb observation and every integer output: BIT-EXACT vs the oracle;
+  * pose / CTE / heading / distances: here also bit-exact vs the oracle in ORC_MATH_PORTABLE mode
+    (same IEEE operation sequence on both sides), and within 1e-9 abs of the reference's goldens
+    (the north star allows 1e-6).
+"""
+import copy
+
+import numpy as np
+import pytest
+
+import orc
+from common import cam_keys, golden, load_cfg, map_of, rollout_files, setup
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+STATE_F = ("x", "y", "theta", "velocity", "steering", "radius", "front_x", "front_y")
+
+
+def make_env(map_name, res_key, fmt, n, **kw):
+    from tinycarlo_amd.vec_env import TinyCarloVecEnv
+    cfg, _ = load_cfg(map_name)
+    cfg = copy.deepcopy(cfg)
+    from common import RES
+    cfg["camera"]["resolution"] = list(RES[res_key])
+    cam_over = kw.pop("camera", {})
+    cfg["camera"].update(cam_over)
+    cfg["sim"]["observation_space_format"] = fmt
+    from tinycarlo_amd.config import bundled_config
+    import os
+    cfg["map"]["json_path"] = os.path.join(os.path.dirname(bundled_config("config_simple_layout.yaml")),
+                                           cfg["map"]["json_path"])
+    return TinyCarloVecEnv(cfg, num_envs=n, device="cuda:0", **kw)
+
+
+def make_oracle(env, threads=8):
+    fmt = orc.FMT_CLASSES if env.observation_space_format == "classes" else orc.FMT_RGB
+    o = orc.Oracle(env.map, env.car_params, env.camera, fmt, env.num_envs, threads=threads)
+    return o
+
+
+def push_state(env, st):
+    """numpy structured oracle state -> the env's device tensors"""
+    for k in STATE_F:
+        env.state[k].copy_(torch.from_numpy(np.ascontiguousarray(st[k])))
+    env.state["local_path"].copy_(torch.from_numpy(np.ascontiguousarray(st["lp"])))
+    env.state["lp_len"].copy_(torch.from_numpy(np.ascontiguousarray(st["lp_len"])))
+    env.state["last_maneuver"].copy_(torch.from_numpy(np.ascontiguousarray(st["last_maneuver"])))
+    env._was_reset = True
+
+
+def assert_same(env, o, C, check_obs=True, label=""):
+    """bit-exact comparison of everything the step produces"""
+    torch.cuda.synchronize()
+    for k in STATE_F:
+        g = env.state[k].cpu().numpy()
+        bad = np.flatnonzero(g.view(np.int64) != o.state[k].view(np.int64))
+        # NaN payloads aside, require identical bits
+        assert bad.size == 0, (label, k, bad[:5], g[bad[:5]], o.state[k][bad[:5]])
+    n = o.state["lp_len"]
+    assert np.array_equal(env.state["lp_len"].cpu().numpy(), n), label
+    valid = np.arange(8)[None, :] < 2 * n[:, None]
+    assert np.array_equal(np.where(valid, env.state["local_path"].cpu().numpy(), -1), np.where(valid, o.state["lp"], -1)), label
+    assert np.array_equal(env.state["last_maneuver"].cpu().numpy(), o.state["last_maneuver"]), label
+    inf = o.info
+    for k in ("cte", "heading_error", "reward"):
+        g = env.out[k].cpu().numpy()
+        assert np.array_equal(g.view(np.int64), inf[k].view(np.int64)), (label, k, np.abs(g - inf[k]).max())
+    assert np.array_equal(env.out["terminated"].cpu().numpy().astype(bool), inf["terminated"].astype(bool)), label
+    assert np.array_equal(env.out["truncated"].cpu().numpy().astype(bool), inf["truncated"].astype(bool)), label
+    assert np.array_equal(env.out["status"].cpu().numpy() & 3, inf["status"] & 3), label
+    gd = env.out["laneline_distances"].cpu().numpy()
+    assert np.array_equal(gd.view(np.int64), inf["dist"][:, :C].copy().view(np.int64)), (label, np.abs(gd - inf["dist"][:, :C]).max())
+    assert np.array_equal(env.out["nearest_edge"].cpu().numpy(), inf["nearest_edge"][:, :C]), label
+    if check_obs:
+        g = env.out["obs"].cpu().numpy().reshape(env.num_envs, -1)
+        diff = np.flatnonzero((g != o.obs).any(axis=1))
+        assert diff.size == 0, (label, "obs differs in envs", diff[:10], int((g != o.obs).sum()))
+
+
+@pytest.fixture(autouse=True)
+def _portable():
+    orc.set_math_mode(orc.MATH_PORTABLE)
+    yield
+    orc.set_math_mode(orc.MATH_LIBM)
+
+
+def _states_from(d, prefix):
+    n = len(d[f"{prefix}x"])
+    s = np.zeros(n, dtype=orc.STATE_DTYPE)
+    for k in STATE_F + ("lp_len", "last_maneuver"):
+        s[k] = d[f"{prefix}{k}"]
+    s["lp"] = d[f"{prefix}lp"].reshape(n, 8)
+    return s
+
+
+@pytest.mark.parametrize("fname", rollout_files())
+def test_golden_teacher_forced(fname):
+    """Every recorded reference step replayed on the GPU from the reference's pre-step state:
+    exact vs oracle, 1e-9 vs the reference; frames exact vs oracle raster of the same state."""
+    d = golden(fname)
+    mp = map_of(fname)
+    k = cam_keys(d)[0]
+    T = len(d["v"])
+    env = make_env(mp, k, "classes", T)
+    o = make_oracle(env)
+    C = env.n_classes
+    pre = _states_from(d, "pre_")
+    o.state[:] = pre
+    push_state(env, pre)
+    cc = np.stack([d["v"], d["s"]], axis=1)
+    o.step(cc, d["maneuver"], flags=0)
+    env.step({"car_control": cc, "maneuver": d["maneuver"]})
+    assert_same(env, o, C, label=fname)
+    # vs the reference itself
+    for key in STATE_F:
+        assert np.abs(env.state[key].cpu().numpy() - d[f"post_{key}"]).max() <= 1e-9, key
+    assert np.abs(env.out["cte"].cpu().numpy() - d["cte"]).max() <= 1e-9
+    assert np.abs(env.out["heading_error"].cpu().numpy() - d["heading_error"]).max() <= 1e-9
+    assert np.abs(env.out["laneline_distances"].cpu().numpy() - d["dist"]).max() <= 1e-9
+    has = d["n_lp_coords"] >= 2
+    assert np.array_equal(env.out["nearest_edge"].cpu().numpy()[has], d["nearest_edge"][has])
+    assert np.array_equal(env.out["truncated"].cpu().numpy().astype(bool), d["truncated"].astype(bool))
+    assert np.array_equal(env.out["terminated"].cpu().numpy().astype(bool), d["terminated"].astype(bool))
+    n = d["post_lp_len"]
+    valid = np.arange(8)[None, :] < 2 * n[:, None]
+    assert np.array_equal(np.where(valid, env.state["local_path"].cpu().numpy(), -1),
+                          np.where(valid, d["post_lp"].reshape(T, 8), -1))
+    env.close()
+
+
+@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen"])
+def test_golden_single_steps(mp):
+    d = golden(f"single_{mp}.npz")
+    T = len(d["v"])
+    env = make_env(mp, "r64", "classes", T)
+    env.wrapped = True
+    o = make_oracle(env)
+    pre = _states_from(d, "pre_")
+    o.state[:] = pre
+    push_state(env, pre)
+    cc = np.stack([d["v"], d["s"]], axis=1)
+    o.step(cc, d["maneuver"], flags=orc.F_WRAPPED)
+    env.step({"car_control": cc, "maneuver": d["maneuver"]})
+    assert_same(env, o, env.n_classes, label=mp)
+    for key in STATE_F:
+        assert np.abs(env.state[key].cpu().numpy() - d[f"post_{key}"]).max() <= 1e-9, key
+    assert np.array_equal(env.out["truncated"].cpu().numpy().astype(bool), d["truncated"].astype(bool))
+    env.close()
+
+
+CASES = [
+    # (map, resolution key, format, N envs, steps, thickness)
+    ("simple_layout", "r64", "classes", 512, 96, 2),     # BASELINE config 3 shape
+    ("knuffingen", "r128", "classes", 256, 64, 2),       # BASELINE config 4 shape
+    ("simple_layout", "r64", "rgb", 128, 48, 2),
+    ("knuffingen", "r64", "classes", 128, 48, 1),        # thickness 1: Bresenham path
+    ("simple_layout", "r128", "rgb", 64, 32, 6),         # stanley_control.py thickness
+    ("knuffingen", "r480", "rgb", 16, 12, 2),            # BASELINE config 5 shape (banded raster)
+    ("simple_layout", "r480", "classes", 8, 8, 3),
+]
+
+
+@pytest.mark.parametrize("mp,rk,fmt,N,steps,th", CASES)
+def test_free_running_vs_oracle(mp, rk, fmt, N, steps, th):
+    """N envs, random actions incl. out-of-range controls and all maneuvers, device-side auto-reset:
+    the GPU and the oracle must stay bit-identical for the whole rollout (state, info, frames)."""
+    env = make_env(mp, rk, fmt, N, autoreset=True, camera={"line_thickness": th}, spawn_queue_len=8)
+    o = make_oracle(env)
+    C = env.n_classes
+    env.reset(seed=123)
+    o.spawn_queue = env._aux["spawn_queue"].cpu().numpy()
+    o.spawn_cursor[:] = 0
+    o.needs_reset[:] = 0
+    o.reset(env._keep[0].cpu().numpy())
+    assert_same(env, o, C, label="reset")
+    rng = np.random.default_rng(5)
+    man = rng.integers(0, 4, N).astype(np.int32)
+    n_reset = 0
+    for t in range(steps):
+        if t % 8 == 0:
+            man = rng.integers(0, 4, N).astype(np.int32)
+        cc = np.stack([rng.uniform(-0.3, 1.2, N), rng.uniform(-1.2, 1.2, N)], axis=1).astype(np.float32)
+        n_reset += int(o.needs_reset.sum())
+        o.step(cc.astype(np.float64), man, flags=orc.F_AUTORESET)
+        env.step({"car_control": cc, "maneuver": man})
+        assert_same(env, o, C, check_obs=(t % 4 == 3 or t == steps - 1), label=f"{mp}/{rk}/{fmt} step {t}")
+        assert np.array_equal(env._aux["needs_reset"].cpu().numpy(), o.needs_reset)
+    assert int(env.out["obs"].max()) > 0
+    env.close()
+
+
+def test_no_observation_and_wrapped_flags():
+    env = make_env("simple_layout", "r64", "classes", 64)
+    o = make_oracle(env)
+    env.reset(seed=3)
+    o.reset(env._keep[0].cpu().numpy())
+    env.no_observation = True
+    env.wrapped = True
+    before = env.out["obs"].clone()
+    rng = np.random.default_rng(0)
+    for t in range(5):
+        cc = np.stack([rng.uniform(0.3, 1, 64), rng.uniform(-1, 1, 64)], axis=1)
+        man = rng.integers(0, 4, 64).astype(np.int32)
+        o.step(cc, man, flags=orc.F_WRAPPED | orc.F_NO_OBSERVATION)
+        obs, rew, term, trunc, info = env.step({"car_control": cc, "maneuver": man})
+        assert_same(env, o, env.n_classes, check_obs=False)
+        assert int(obs.max()) == 0 and float(rew.abs().max()) == 0 and not bool(term.any())
+    assert torch.equal(before, env.out["obs"])  # frame buffer untouched
+    env.close()
+
+
+def test_f32_and_f64_actions_agree_on_f32_values():
+    env = make_env("simple_layout", "r64", "classes", 32)
+    env.reset(seed=1)
+    snap = {k: v.clone() for k, v in env.state.items()}
+    rng = np.random.default_rng(2)
+    cc = np.stack([rng.uniform(0.3, 1, 32), rng.uniform(-1, 1, 32)], axis=1).astype(np.float32)
+    man = rng.integers(0, 4, 32).astype(np.int32)
+    env.step({"car_control": cc, "maneuver": man})
+    a = {k: v.clone() for k, v in env.state.items()}
+    for k, v in snap.items():
+        env.state[k].copy_(v)
+    env.step({"car_control": cc.astype(np.float64), "maneuver": man})
+    for k in a:
+        assert torch.equal(a[k], env.state[k]), k
+    env.close()
+
+
+def test_camera_update_params():
+    """camera.orientation / fov changed at run time + update_params() (train_stanley_il.py:55-57)."""
+    env = make_env("simple_layout", "r64", "classes", 16)
+    o = make_oracle(env)
+    env.reset(seed=9)
+    o.reset(env._keep[0].cpu().numpy())
+    env.camera.orientation = [30, 2, -3]
+    env.camera.fov = 95
+    env.camera.update_params()
+    o.set_camera(env.camera)
+    cc = np.tile(np.array([[0.6, 0.1]]), (16, 1))
+    man = np.zeros(16, dtype=np.int32)
+    o.step(cc, man)
+    env.step({"car_control": cc, "maneuver": man})
+    assert_same(env, o, env.n_classes)
+    env.close()

@@ -1,0 +1,648 @@
+// tc_device.h -- device-side building blocks of the batched tinycarlo step (gfx950 / CDNA4).
+//
+// Everything here is double precision with the reference's own formulation (no FMA contraction:
+// the library is built with -ffp-contract=off), transcendental functions from tc_trig.h, and static
+// edge orientations read from tables computed on the host with libm (they are constants of the
+// map; the reference evaluates math.atan2 on them at run time, layer.py:122,140-141,181).
+//
+// Execution model: ONE WAVEFRONT (64 lanes) PER ENV.  Scalar per-env work (kinematics, lanepath
+// tracking) is computed redundantly by all lanes (same wave-instruction count as one active lane,
+// no LDS broadcast needed); data-parallel work (argmin over edges, node transforms, segment
+// rasterisation, observation stores) is strided over the 64 lanes.
+#ifndef TC_DEVICE_H
+#define TC_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tc_trig.h"
+
+#define TC_NT 64  // threads per workgroup == wavefront size
+#define TC_PI 3.141592653589793
+
+struct DevMap {
+  int C;
+  int node_off[17];
+  int edge_off[17];
+  int max_nodes, max_edges, total_nodes, total_edges;
+  const double2* nodes;   // lane-line nodes, all layers concatenated
+  const int2* edges;      // lane-line edges (layer-local node ids)
+  const double* ori_fwd;  // per lane-line edge: atan2(evy, evx)
+  const double* ori_rev;  // per lane-line edge: atan2(-evy, -evx)
+  unsigned char colors[16][3];
+  int lpN, lpE;
+  int first_spawnable;    // a lanepath node with an out-edge (fallback for invalid spawn requests)
+  const double2* lp_nodes;
+  const int2* lp_edges;
+  const double* lp_ori;   // per lanepath edge orientation
+  const int* next_off;    // CSR of get_next_nodes (edge-list order kept)
+  const int* next_node;
+  const double* next_ori;
+  const int* prev_off;    // CSR of get_prev_nodes
+  const int* prev_node;
+  const double* prev_ori;
+};
+
+struct DevCar {
+  double T, wheelbase, track_width, max_velocity, max_steering_angle;
+  double steering_speed, max_acceleration, max_deceleration;
+  int has_steering_speed, has_max_acceleration;
+};
+
+struct DevCam {
+  int H, W;
+  double E[12];
+  double K[9];
+  double max_range;
+  int thickness;
+  int format;
+  int wpr;        // 32-bit words per bit-plane row
+  int band_rows;  // rows rasterised per pass (bit-planes of one band live in LDS)
+  int n_bands;
+};
+
+struct CarState {
+  double x, y, theta, velocity, steering, radius, front_x, front_y;
+  int lp[8];
+  int lp_len, last_maneuver;
+};
+
+// ------------------------------------------------------------------ scalar helpers
+__device__ inline double d_clip_angle(double a) {  // helper.py:11-19 (bounded, see oracle)
+  int guard = 0;
+  while (a > TC_PI && guard++ < 64) a -= 2 * TC_PI;
+  while (a < -TC_PI && guard++ < 128) a += 2 * TC_PI;
+  return a;
+}
+
+__device__ inline double d_np_clip(double x, double lo, double hi) {  // numpy clip ufunc
+  double m = (x != x) ? x : (x > lo ? x : lo);
+  return (m != m) ? m : (m < hi ? m : hi);
+}
+
+__device__ inline double d_dist(double ax, double ay, double bx, double by) {  // layer.py:187
+  double dx = ax - bx, dy = ay - by;
+  return sqrt(dx * dx + dy * dy);
+}
+
+__device__ inline double d_radians(double d) { return d * (TC_PI / 180.0); }
+
+// lowest-index argmin across the wave; idx < 0 means "no candidate"
+__device__ inline void wave_argmin(double& v, int& idx) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double ov = __shfl_down(v, off);
+    int oi = __shfl_down(idx, off);
+    bool take = (oi >= 0) && (idx < 0 || ov < v || (ov == v && oi < idx));
+    if (take) {
+      v = ov;
+      idx = oi;
+    }
+  }
+  v = __shfl(v, 0);
+  idx = __shfl(idx, 0);
+}
+
+// ------------------------------------------------------------------ layer.py
+// layer.py:144-164
+__device__ inline double d_distance_to_edge(double n1x, double n1y, double n2x, double n2y, double px, double py) {
+  double lvx = n2x - n1x, lvy = n2y - n1y;
+  double pvx = px - n1x, pvy = py - n1y;
+  if (lvx == 0) {
+    if (lvy > 0) return px - n1x;
+    return n1x - px;
+  }
+  return (pvx * lvy - pvy * lvx) / sqrt(lvx * lvx + lvy * lvy);
+}
+
+// layer.py:126-142
+__device__ inline bool d_within_bounds(double n0x, double n0y, double n1x, double n1y, double ori_fwd, double ori_rev,
+                                       double px, double py) {
+  if (px == n0x && py == n0y) return true;
+  if (px == n1x && py == n1y) return true;
+  double a0 = tc_fabs(d_clip_angle(tc_atan2(py - n0y, px - n0x) - ori_fwd));
+  double a1 = tc_fabs(d_clip_angle(tc_atan2(py - n1y, px - n1x) - ori_rev));
+  return a0 <= TC_PI / 2 && a1 <= TC_PI / 2;
+}
+
+// layer.py:179-181 for a lanepath edge (a,b): table entry of the first a->b edge
+__device__ inline double d_lp_edge_ori(const DevMap& m, int a, int b) {
+  int s0 = m.next_off[a], s1 = m.next_off[a + 1];
+  for (int s = s0; s < s1; s++)
+    if (m.next_node[s] == b) return m.next_ori[s];
+  double2 na = m.lp_nodes[a], nb = m.lp_nodes[b];
+  return tc_atan2(nb.y - na.y, nb.x - na.x);
+}
+
+// layer.py:105-124 on a CSR slice; returns node id or -1 (None)
+__device__ inline int d_pick_node(const int* lst, const double* ori, int s0, int s1, int node_idx, double orientation,
+                                  int& status) {
+  int n = s1 - s0;
+  if (n == 0) return -1;
+  if (n <= 1) return lst[s0];
+  int best = -1, k = 0;
+  double bk = 0;
+  for (int s = s0; s < s1; s++) {
+    if (lst[s] == node_idx) continue;
+    double key = tc_fabs(d_clip_angle(ori[s] - orientation));
+    if (best < 0 || key < bk) {
+      best = k;
+      bk = key;
+    }
+    k++;
+  }
+  if (best < 0) {
+    status |= 2;  // TC_S_PICK_EMPTY
+    return -1;
+  }
+  return lst[s0 + best];
+}
+
+// layer.py:59-74 over the lanepath, all 64 lanes cooperating; returns edge index or -1
+__device__ inline int d_nearest_edge_with_orientation(const DevMap& m, double px, double py, double orientation,
+                                                      double margin_deg) {
+  const int tid = threadIdx.x;
+  double lim = d_radians(margin_deg);
+  int best = -1;
+  double bd = 0;
+  for (int e = tid; e < m.lpE; e += TC_NT) {
+    if (!(tc_fabs(d_clip_angle(m.lp_ori[e] - orientation)) <= lim)) continue;
+    int2 ed = m.lp_edges[e];
+    double2 a = m.lp_nodes[ed.x], b = m.lp_nodes[ed.y];
+    double d = tc_fabs(d_dist(px, py, a.x, a.y) + d_dist(px, py, b.x, b.y));
+    if (best < 0 || d < bd) {
+      best = e;
+      bd = d;
+    }
+  }
+  wave_argmin(bd, best);
+  return best;
+}
+
+// ------------------------------------------------------------------ car.py
+__device__ inline void d_update_front(const DevCar& c, CarState& s) {  // car.py:167-168
+  s.front_x = s.x + c.wheelbase * tc_cos(s.theta);
+  s.front_y = s.y + c.wheelbase * tc_sin(s.theta);
+}
+
+// car.py:34-44 + map.py:62-69 with the spawn node already drawn
+__device__ inline void d_reset(const DevMap& m, const DevCar& c, CarState& s, int node) {
+  int s0 = m.next_off[node];
+  double2 p = m.lp_nodes[node];
+  s.x = p.x;
+  s.y = p.y;
+  s.theta = m.next_ori[s0];
+#pragma unroll
+  for (int i = 0; i < 8; i++) s.lp[i] = -1;
+  s.lp[0] = node;
+  s.lp[1] = m.next_node[s0];
+  s.lp_len = 1;
+  d_update_front(c, s);
+  s.steering = 0.0;
+  s.radius = 0.0;
+  s.velocity = 0.0;
+  s.last_maneuver = 0;
+}
+
+// car.py:127-148
+__device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuver, int& status) {
+  double fx = s.front_x, fy = s.front_y;
+  int e0 = s.lp[0], e1 = s.lp[1];
+  double mdir = d_clip_angle(d_lp_edge_ori(m, e0, e1) + (maneuver * TC_PI) / 2);
+  int ne0, ne1;
+  if (maneuver == 2 && s.last_maneuver != 2) {  // wave-uniform branch
+    int e = d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0);
+    mdir = d_clip_angle(mdir + TC_PI);
+    if (e < 0) {
+      status |= 1;  // TC_S_UTURN_NO_EDGE
+      return 1;
+    }
+    int2 ed = m.lp_edges[e];
+    ne0 = ed.x;
+    ne1 = ed.y;
+  } else {  // layer.py:77-103
+    int nx = d_pick_node(m.next_node, m.next_ori, m.next_off[e1], m.next_off[e1 + 1], e1, mdir, status);
+    int pv = d_pick_node(m.prev_node, m.prev_ori, m.prev_off[e0], m.prev_off[e0 + 1], e0, mdir, status);
+    if (nx < 0 || pv < 0) return 1;
+    double2 n0 = m.lp_nodes[e0], n1 = m.lp_nodes[e1], nn = m.lp_nodes[nx], np = m.lp_nodes[pv];
+    double d0 = d_dist(fx, fy, n0.x, n0.y), d1 = d_dist(fx, fy, n1.x, n1.y);
+    double dn = d_dist(fx, fy, nn.x, nn.y), dp = d_dist(fx, fy, np.x, np.y);
+    if (dn < d0 && dn < d1) {
+      ne0 = e1;
+      ne1 = nx;
+    } else if (dp < d0 && dp < d1) {
+      ne0 = pv;
+      ne1 = e0;
+    } else {
+      ne0 = e0;
+      ne1 = e1;
+    }
+  }
+  s.last_maneuver = maneuver;
+  s.lp[0] = ne0;
+  s.lp[1] = ne1;
+  s.lp_len = 1;
+  int last0 = ne0, last1 = ne1;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    int node = s.velocity > 0 ? last1 : last0;  // car.py:143
+    int nn = d_pick_node(m.next_node, m.next_ori, m.next_off[node], m.next_off[node + 1], node, mdir, status);
+    if (nn < 0) return 1;
+    s.lp[2 * (i + 1)] = node;
+    s.lp[2 * (i + 1) + 1] = nn;
+    s.lp_len = i + 2;
+    last0 = node;
+    last1 = nn;
+  }
+  return 0;
+}
+
+// car.py:70-125; returns truncated
+__device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, double v_in, double s_in, int maneuver,
+                                 int& status) {
+  double dt = c.T;
+  double nv = v_in * c.max_velocity;
+  if (c.has_max_acceleration)
+    nv = d_np_clip(nv, s.velocity - c.max_deceleration * dt, s.velocity + c.max_acceleration * dt);
+  s.velocity = nv;
+  double ns = s_in * c.max_steering_angle;
+  if (c.has_steering_speed) ns = d_np_clip(ns, s.steering - c.steering_speed * dt, s.steering + c.steering_speed * dt);
+  s.steering = ns;
+  double vxn = tc_cos(s.theta), vyn = tc_sin(s.theta);
+  if (tc_fabs(s.steering) < 0.0001) {
+    s.radius = 0;
+    s.x = s.x + s.velocity * vxn * dt;
+    s.y = s.y + s.velocity * vyn * dt;
+  } else {
+    s.radius = c.wheelbase / tc_tan(d_radians(s.steering));
+    double ang_vel = s.velocity / s.radius;
+    double dyaw = ang_vel * dt;
+    double nx = vyn, ny = -vxn;
+    double tx = nx * s.radius, ty = ny * s.radius;
+    double cd = tc_cos(dyaw), sd = tc_sin(dyaw);
+    double r0 = cd * tx + (-sd) * ty;
+    double r1 = sd * tx + cd * ty;
+    s.x = s.x - tx + r0;
+    s.y = s.y - ty + r1;
+    s.theta += dyaw;
+    if (s.theta > TC_PI)
+      s.theta -= 2 * TC_PI;
+    else if (s.theta < -TC_PI)
+      s.theta += 2 * TC_PI;
+  }
+  d_update_front(c, s);
+  return d_find_local_path(m, s, maneuver, status);
+}
+
+// ------------------------------------------------------------------ camera.py helpers
+// C[i][j] = sum_t A[i][t] * B[t][j], t ascending (same association as the oracle)
+template <int N, int K, int P>
+__device__ inline void d_matmul(const double* A, const double* B, double* C) {
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+      double acc = A[i * K] * B[j];
+#pragma unroll
+      for (int t = 1; t < K; t++) acc += A[i * K + t] * B[t * P + j];
+      C[i * P + j] = acc;
+    }
+}
+
+// np.int32(float64) as x86-64 does it: out of range / NaN -> INT_MIN
+__device__ inline int d_np_int32(double v) {
+  if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+  return (int)v;
+}
+
+// ------------------------------------------------------------------ cv2.polylines restated on LDS bit-planes
+// One bit per pixel and layer; `bits` points at the plane of the segment's layer for the current band.
+#define TC_XY_SHIFT 16
+#define TC_XY_ONE 65536
+
+struct Ras {
+  unsigned int* bits;
+  int W, H, wpr;
+  int y0, y1;  // band rows [y0, y1)
+};
+
+__device__ inline int d_wrap32(long long v) { return (int)(unsigned int)(unsigned long long)v; }
+
+__device__ inline void r_put(const Ras& r, int x, int y) {
+  if ((unsigned)x >= (unsigned)r.W || y < r.y0 || y >= r.y1) return;
+  atomicOr(&r.bits[(y - r.y0) * r.wpr + (x >> 5)], 1u << (x & 31));
+}
+
+// inclusive span [xl, xr] on row y
+__device__ inline void r_hline(const Ras& r, int y, int xl, int xr) {
+  if (y < r.y0 || y >= r.y1) return;
+  if (xl < 0) xl = 0;
+  if (xr > r.W - 1) xr = r.W - 1;
+  if (xl > xr) return;
+  unsigned int* row = r.bits + (y - r.y0) * r.wpr;
+  int w0 = xl >> 5, w1 = xr >> 5;
+  for (int w = w0; w <= w1; w++) {
+    unsigned int mk = 0xffffffffu;
+    if (w == w0) mk &= 0xffffffffu << (xl & 31);
+    if (w == w1) mk &= 0xffffffffu >> (31 - (xr & 31));
+    atomicOr(&row[w], mk);
+  }
+}
+
+// clipLine(Size2l, Point2l&, Point2l&)
+__device__ inline bool r_clip_line(long long width, long long height, long long& x1, long long& y1, long long& x2,
+                                   long long& y2) {
+  int c1, c2;
+  long long right = width - 1, bottom = height - 1;
+  if (width <= 0 || height <= 0) return false;
+  c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+  c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+    long long a;
+    if (c1 & 12) {
+      a = c1 < 8 ? 0 : bottom;
+      x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+      y1 = a;
+      c1 = (x1 < 0) + (x1 > right) * 2;
+    }
+    if (c2 & 12) {
+      a = c2 < 8 ? 0 : bottom;
+      x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+      y2 = a;
+      c2 = (x2 < 0) + (x2 > right) * 2;
+    }
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+      if (c1) {
+        a = c1 == 1 ? 0 : right;
+        y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+        x1 = a;
+        c1 = 0;
+      }
+      if (c2) {
+        a = c2 == 1 ? 0 : right;
+        y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+        x2 = a;
+        c2 = 0;
+      }
+    }
+  }
+  return (c1 | c2) == 0;
+}
+
+// Line(): LineIterator(..., 8, leftToRight=true) -- thickness <= 1
+__device__ inline void r_line_bresenham(const Ras& r, long long x1, long long y1, long long x2, long long y2) {
+  if ((unsigned long long)x1 >= (unsigned long long)r.W || (unsigned long long)x2 >= (unsigned long long)r.W ||
+      (unsigned long long)y1 >= (unsigned long long)r.H || (unsigned long long)y2 >= (unsigned long long)r.H) {
+    if (!r_clip_line(r.W, r.H, x1, y1, x2, y2)) return;
+  }
+  long long dx = x2 - x1, dy = y2 - y1;
+  int sy = 1;
+  if (dx < 0) {
+    dx = -dx;
+    dy = -dy;
+    x1 = x2;
+    y1 = y2;
+  }
+  if (dy < 0) {
+    dy = -dy;
+    sy = -1;
+  }
+  bool vert = dy > dx;
+  if (vert) {
+    long long t = dx;
+    dx = dy;
+    dy = t;
+  }
+  long long err = dx - (dy + dy), plus = dx + dx, minus = -(dy + dy);
+  int count = (int)dx + 1;
+  int x = (int)x1, y = (int)y1;
+  for (int i = 0; i < count; i++) {
+    r_put(r, x, y);
+    bool mask = err < 0;
+    err += minus + (mask ? plus : 0);
+    if (vert) {
+      y += sy;
+      if (mask) x += 1;
+    } else {
+      x += 1;
+      if (mask) y += sy;
+    }
+  }
+}
+
+// Line2(): 16.16 fixed-point DDA (polygon outline)
+__device__ inline void r_line2(const Ras& r, long long p1x, long long p1y, long long p2x, long long p2y) {
+  if (!r_clip_line((long long)r.W << TC_XY_SHIFT, (long long)r.H << TC_XY_SHIFT, p1x, p1y, p2x, p2y)) return;
+  long long dx = p2x - p1x, dy = p2y - p1y;
+  long long j = dx < 0 ? -1 : 0;
+  long long ax = (dx ^ j) - j;
+  long long i = dy < 0 ? -1 : 0;
+  long long ay = (dy ^ i) - i;
+  long long x_step, y_step;
+  int ecount;
+  bool xmajor = ax > ay;
+  if (xmajor) {
+    dy = (dy ^ j) - j;
+    if (j) {
+      long long t = p1x; p1x = p2x; p2x = t;
+      t = p1y; p1y = p2y; p2y = t;
+    }
+    x_step = TC_XY_ONE;
+    y_step = (dy * TC_XY_ONE) / (ax | 1);
+    ecount = (int)((p2x - p1x) >> TC_XY_SHIFT);
+  } else {
+    dx = (dx ^ i) - i;
+    if (i) {
+      long long t = p1x; p1x = p2x; p2x = t;
+      t = p1y; p1y = p2y; p2y = t;
+    }
+    x_step = (dx * TC_XY_ONE) / (ay | 1);
+    y_step = TC_XY_ONE;
+    ecount = (int)((p2y - p1y) >> TC_XY_SHIFT);
+  }
+  p1x += (TC_XY_ONE >> 1);
+  p1y += (TC_XY_ONE >> 1);
+  r_put(r, (int)((p2x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), (int)((p2y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT));
+  if (xmajor) {
+    p1x >>= TC_XY_SHIFT;
+    while (ecount >= 0) {
+      r_put(r, (int)p1x, (int)(p1y >> TC_XY_SHIFT));
+      p1x++;
+      p1y += y_step;
+      ecount--;
+    }
+  } else {
+    p1y >>= TC_XY_SHIFT;
+    while (ecount >= 0) {
+      r_put(r, (int)(p1x >> TC_XY_SHIFT), (int)p1y);
+      p1x += x_step;
+      p1y++;
+      ecount--;
+    }
+  }
+}
+
+__device__ inline long long pick4(const long long* v, int i) {  // register-resident v[i]
+  long long r = v[0];
+  r = i == 1 ? v[1] : r;
+  r = i == 2 ? v[2] : r;
+  r = i == 3 ? v[3] : r;
+  return r;
+}
+
+// FillConvexPoly(v[4], shift = 16), LINE_8
+__device__ inline void r_fill_convex_poly4(const Ras& r, const long long* vx, const long long* vy) {
+  const int npts = 4, shift = TC_XY_SHIFT;
+  const int delta = 1 << shift >> 1;
+  int e_idx[2], e_di[2], e_ye[2];
+  long long e_x[2], e_dx[2];
+  int imin = 0;
+  int edges = npts;
+  long long xmin, xmax, ymin, ymax;
+  long long p0x = vx[3], p0y = vy[3];
+  xmin = xmax = vx[0];
+  ymin = ymax = vy[0];
+#pragma unroll
+  for (int i = 0; i < npts; i++) {
+    long long px = vx[i], py = vy[i];
+    if (py < ymin) {
+      ymin = py;
+      imin = i;
+    }
+    if (py > ymax) ymax = py;
+    if (px > xmax) xmax = px;
+    if (px < xmin) xmin = px;
+    r_line2(r, p0x, p0y, px, py);
+    p0x = px;
+    p0y = py;
+  }
+  xmin = (xmin + delta) >> shift;
+  xmax = (xmax + delta) >> shift;
+  ymin = (ymin + delta) >> shift;
+  ymax = (ymax + delta) >> shift;
+  if (d_wrap32(xmax) < 0 || d_wrap32(ymax) < 0 || d_wrap32(xmin) >= r.W || d_wrap32(ymin) >= r.H) return;
+  if (ymax > r.H - 1) ymax = r.H - 1;
+  int y = d_wrap32(ymin);
+  e_idx[0] = e_idx[1] = imin;
+  e_ye[0] = e_ye[1] = y;
+  e_di[0] = 1;
+  e_di[1] = npts - 1;
+  e_x[0] = e_x[1] = -TC_XY_ONE;
+  e_dx[0] = e_dx[1] = 0;
+  // rows below draw_lo are walked in closed form (OpenCV walks negative rows one at a time; rows
+  // above the current band are handled identically: nothing but x += dx happens there)
+  const int draw_lo = r.y0 > 0 ? r.y0 : 0;
+  const int last = (int)ymax < r.y1 - 1 ? (int)ymax : r.y1 - 1;  // rows past the band end cannot matter
+  if (y > last) return;
+  do {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (y >= e_ye[i]) {
+        int idx0 = e_idx[i], di = e_di[i];
+        int idx = idx0 + di;
+        if (idx >= npts) idx -= npts;
+        for (; edges-- > 0;) {
+          int ty = d_wrap32((pick4(vy, idx) + delta) >> shift);
+          if (ty > y) {
+            long long xs = pick4(vx, idx0), xe = pick4(vx, idx);
+            e_ye[i] = ty;
+            e_dx[i] = ((xe - xs) * 2 + ((long long)ty - y)) / (2 * ((long long)ty - y));
+            e_x[i] = xs;
+            e_idx[i] = idx;
+            break;
+          }
+          idx0 = idx;
+          idx += di;
+          if (idx >= npts) idx -= npts;
+        }
+      }
+    }
+    if (edges < 0) break;
+    if (y >= draw_lo) {
+      long long xl = e_x[0], xr = e_x[1];
+      if (xl > xr) {
+        long long t = xl;
+        xl = xr;
+        xr = t;
+      }
+      int xx1 = d_wrap32((xl + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
+      int xx2 = d_wrap32((xr + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
+      if (xx2 >= 0 && xx1 < r.W) r_hline(r, y, xx1, xx2);
+      e_x[0] += e_dx[0];
+      e_x[1] += e_dx[1];
+    } else {
+      long long nxt = draw_lo;
+      if (e_ye[0] < nxt) nxt = e_ye[0];
+      if (e_ye[1] < nxt) nxt = e_ye[1];
+      if (ymax + 1 < nxt) nxt = ymax + 1;
+      long long k = nxt - y;
+      if (k < 1) k = 1;
+      e_x[0] += e_dx[0] * k;
+      e_x[1] += e_dx[1] * k;
+      y += (int)(k - 1);
+    }
+  } while (++y <= last);
+}
+
+// Circle(center, radius, fill)
+__device__ inline void r_circle_fill(const Ras& r, int cx, int cy, int radius) {
+  int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+  const int W = r.W, H = r.H;
+  bool inside = cx >= radius && cx < W - radius && cy >= radius && cy < H - radius;
+  while (dx >= dy) {
+    long long y11 = (long long)cy - dy, y12 = (long long)cy + dy, y21 = (long long)cy - dx, y22 = (long long)cy + dx;
+    long long x11 = (long long)cx - dx, x12 = (long long)cx + dx, x21 = (long long)cx - dy, x22 = (long long)cx + dy;
+    if (inside) {
+      r_hline(r, (int)y11, (int)x11, (int)x12);
+      r_hline(r, (int)y12, (int)x11, (int)x12);
+      r_hline(r, (int)y21, (int)x21, (int)x22);
+      r_hline(r, (int)y22, (int)x21, (int)x22);
+    } else if (x11 < W && x12 >= 0 && y21 < H && y22 >= 0) {
+      if (x11 < 0) x11 = 0;
+      if (x12 > W - 1) x12 = W - 1;
+      if (y11 >= 0 && y11 < H) r_hline(r, (int)y11, (int)x11, (int)x12);
+      if (y12 >= 0 && y12 < H) r_hline(r, (int)y12, (int)x11, (int)x12);
+      if (x21 < W && x22 >= 0) {
+        if (x21 < 0) x21 = 0;
+        if (x22 > W - 1) x22 = W - 1;
+        if (y21 >= 0 && y21 < H) r_hline(r, (int)y21, (int)x21, (int)x22);
+        if (y22 >= 0 && y22 < H) r_hline(r, (int)y22, (int)x21, (int)x22);
+      }
+    }
+    dy++;
+    err += plus;
+    plus += 2;
+    int mask = (err <= 0) - 1;
+    err -= minus & mask;
+    dx += mask;
+    minus -= mask & 2;
+  }
+}
+
+// PolyLine(open, 2 points) -> ThickLine(p0, p1, thickness, LINE_8, flags = 3, shift = 0)
+__device__ inline void r_thick_line(const Ras& r, int x0, int y0, int x1, int y1, int thickness) {
+  long long p0x = (long long)x0 * TC_XY_ONE, p0y = (long long)y0 * TC_XY_ONE;
+  long long p1x = (long long)x1 * TC_XY_ONE, p1y = (long long)y1 * TC_XY_ONE;
+  if (thickness <= 1) {
+    r_line_bresenham(r, (p0x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT, (p0y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT,
+                     (p1x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT, (p1y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
+    return;
+  }
+  const double INV_XY_ONE = 1. / TC_XY_ONE;
+  double dx = (double)(p0x - p1x) * INV_XY_ONE, dy = (double)(p1y - p0y) * INV_XY_ONE;
+  double rr = dx * dx + dy * dy;
+  int odd = thickness & 1;
+  long long th = (long long)thickness << (TC_XY_SHIFT - 1);
+  if (tc_fabs(rr) > 2.2204460492503131e-16) {
+    rr = ((double)th + odd * TC_XY_ONE * 0.5) / sqrt(rr);
+    long long dpx = __double2int_rn(dy * rr), dpy = __double2int_rn(dx * rr);
+    long long vx[4] = {p0x + dpx, p0x - dpx, p1x - dpx, p1x + dpx};
+    long long vy[4] = {p0y + dpy, p0y - dpy, p1y - dpy, p1y + dpy};
+    r_fill_convex_poly4(r, vx, vy);
+  }
+  int rad = (int)((th + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
+  r_circle_fill(r, d_wrap32((p0x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), d_wrap32((p0y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), rad);
+  r_circle_fill(r, d_wrap32((p1x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), d_wrap32((p1y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), rad);
+}
+
+#endif  // TC_DEVICE_H

@@ -1,0 +1,289 @@
+"""TinyCarloVecEnv -- N independent tinycarlo envs advancing in lockstep on one MI355X.
+
+Same config schema, action / observation / info semantics as the reference's ``TinyCarloEnv``
+(``tinycarlo/env.py:15-147``), batched on a leading ``num_envs`` axis:
+
+* state lives as structure-of-arrays in torch CUDA tensors (``self.state``) that the HIP library
+  reads and writes in place through the C ABI (``include/tinycarlo_hip.h``);
+* ``step(action)`` enqueues ONE kernel launch (kinematics -> lanepath tracking -> lane-line
+  distances -> camera raster) on torch's current stream; observations / rewards / info stay on the
+  device unless ``return_numpy=True``;
+* spawn nodes are drawn on the host with one ``numpy.random.Generator`` per env, seeded like
+  gymnasium seeds ``env.np_random`` (seed + env index), so env ``i`` reproduces the reference env
+  reset with ``seed + i``.
+
+No CPU fallback exists: without the compiled library (or a GPU) construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import gym
+from .camera import Camera
+from .config import CarParams, load_config
+from .map import Map
+
+
+def _default_device() -> torch.device:
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+
+
+class CarView:
+    """What wrappers read from ``env.unwrapped.car`` (``wrapper/reward.py:21,41``): the car constants."""
+
+    def __init__(self, p: CarParams):
+        self.T = p.T
+        self.track_width = p.track_width
+        self.wheelbase = p.wheelbase
+        self.max_velocity = p.max_velocity
+        self.max_steering_angle = p.max_steering_angle
+        self.steering_speed = p.steering_speed
+        self.max_acceleration = p.max_acceleration
+        self.max_deceleration = p.max_deceleration
+
+
+class TinyCarloVecEnv:
+    metadata = {"render_modes": ["rgb_array"]}
+
+    def __init__(self, config: Union[str, Dict[str, Any]], num_envs: Optional[int] = None,
+                 device: Union[None, str, torch.device] = None, render_mode: Optional[str] = None,
+                 return_numpy: bool = False, autoreset: bool = False, spawn_queue_len: int = 64):
+        self.config, self.config_path = load_config(config)
+        sim = self.config["sim"]
+        self.fps: int = sim.get("fps", 30)
+        self.T: float = 1 / self.fps
+        self.observation_space_format: str = sim.get("observation_space_format", "rgb")
+        if self.observation_space_format not in ("rgb", "classes"):
+            raise ValueError("sim.observation_space_format must be 'rgb' or 'classes'")
+        self.num_envs = int(num_envs if num_envs is not None else sim.get("num_envs", 1))
+        if self.num_envs < 1:
+            raise ValueError("num_envs must be >= 1")
+        self.device = torch.device(device) if device is not None else (
+            torch.device(sim["device"]) if "device" in sim else _default_device())
+        if self.device.type != "cuda":
+            raise nat.NativeError("tinycarlo_amd runs on an AMD GPU (device 'cuda:N' under ROCm); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise nat.NativeError("no GPU visible to torch: tinycarlo_amd has no CPU fallback")
+        assert render_mode is None or render_mode in self.metadata["render_modes"]
+        self.render_mode = render_mode
+        self.return_numpy = return_numpy
+        self.autoreset = autoreset
+        self.wrapped = False          # env.py:56
+        self.no_observation = False   # env.py:60
+
+        self.map = Map(self.config["map"], base_path=self.config_path)
+        self.car_params = CarParams.from_config(self.T, self.config["car"])
+        self.car = CarView(self.car_params)
+        self.camera = Camera(self.config["camera"], on_update=self._push_camera)
+        self.layer_names: List[str] = self.map.get_laneline_names()
+        self.n_classes = len(self.layer_names)
+        H, W = self.camera.resolution
+        self._fmt = nat.FMT_CLASSES if self.observation_space_format == "classes" else nat.FMT_RGB
+
+        # spaces (env.py:64-73): per-env spaces; batched tensors carry a leading num_envs axis
+        self.single_action_space = gym.spaces.Dict({
+            "car_control": gym.spaces.Box(-1, 1, shape=(2,), dtype=np.float32),
+            "maneuver": gym.spaces.Discrete(4)})
+        obs_shape = (self.n_classes, H, W) if self._fmt == nat.FMT_CLASSES else (H, W, 3)
+        self.single_observation_space = gym.spaces.Box(low=0, high=255, shape=obs_shape, dtype=np.uint8)
+        self.action_space = self.single_action_space
+        self.observation_space = self.single_observation_space
+
+        L = nat.lib()
+        N, Cn, dev = self.num_envs, self.n_classes, self.device
+        with torch.cuda.device(dev):
+            self._nmap = nat.NativeMap(self.map)
+            h = C.c_void_p()
+            cp = nat.make_car_params(self.car_params)
+            cam = nat.make_camera_params(self.camera, self._fmt)
+            nat.check(L.tc_env_create(self._nmap.handle, C.byref(cp), C.byref(cam), N, C.byref(h)), "tc_env_create")
+            self._h = h
+            f64 = dict(dtype=torch.float64, device=dev)
+            i32 = dict(dtype=torch.int32, device=dev)
+            u8 = dict(dtype=torch.uint8, device=dev)
+            self.state: Dict[str, torch.Tensor] = {
+                "x": torch.zeros(N, **f64), "y": torch.zeros(N, **f64), "theta": torch.zeros(N, **f64),
+                "velocity": torch.zeros(N, **f64), "steering": torch.zeros(N, **f64), "radius": torch.zeros(N, **f64),
+                "front_x": torch.zeros(N, **f64), "front_y": torch.zeros(N, **f64),
+                "local_path": torch.full((N, 8), -1, **i32), "lp_len": torch.zeros(N, **i32),
+                "last_maneuver": torch.zeros(N, **i32)}
+            self.out: Dict[str, torch.Tensor] = {
+                "cte": torch.zeros(N, **f64), "heading_error": torch.zeros(N, **f64), "reward": torch.zeros(N, **f64),
+                "terminated": torch.zeros(N, **u8), "truncated": torch.zeros(N, **u8), "status": torch.zeros(N, **i32),
+                "laneline_distances": torch.zeros((N, Cn), **f64), "nearest_edge": torch.full((N, Cn), -1, **i32),
+                "obs": torch.zeros((N,) + obs_shape, **u8)}
+            self.spawn_queue_len = int(spawn_queue_len)
+            self._aux: Dict[str, torch.Tensor] = {
+                "needs_reset": torch.zeros(N, **u8), "spawn_queue": torch.zeros((N, self.spawn_queue_len), **i32),
+                "spawn_cursor": torch.zeros(N, **i32)}
+            self._lp_nodes = torch.as_tensor(np.asarray(self.map.lanepath.nodes, dtype=np.float64), device=dev)
+            b = nat.Buffers()
+            for k, t in {**self.state, **self.out, **self._aux}.items():
+                setattr(b, k, t.data_ptr())
+            b.spawn_queue_len = self.spawn_queue_len
+            nat.check(L.tc_env_bind(self._h, C.byref(b)), "tc_env_bind")
+        self.obs_bytes_per_env = int(L.tc_env_obs_bytes(self._h))
+        self.lds_bytes = int(L.tc_env_lds_bytes(self._h))
+        self._rngs: List[Optional[np.random.Generator]] = [None] * N
+        self._action_bufs: Dict[Any, torch.Tensor] = {}
+        self._was_reset = False
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def unwrapped(self):
+        return self
+
+    def _flags(self) -> int:
+        f = 0
+        if self.no_observation and self.render_mode is None:  # env.py:78
+            f |= nat.F_NO_OBSERVATION
+        if self.wrapped:
+            f |= nat.F_WRAPPED
+        if self.autoreset:
+            f |= nat.F_AUTORESET
+        return f
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _push_camera(self, cam: Camera) -> None:
+        cp = nat.make_camera_params(cam, self._fmt)
+        nat.check(nat.lib().tc_env_set_camera(self._h, C.byref(cp)), "tc_env_set_camera")
+
+    def _to_dev(self, key: str, a, dtype: torch.dtype, shape: Tuple[int, ...]) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            t = a
+            if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
+                t = t.to(device=self.device, dtype=dtype).contiguous()
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{key} must have shape {shape}, got {tuple(t.shape)}")
+        return t
+
+    def seed_generators(self, seed: Optional[int]) -> None:
+        """env i gets gymnasium's np_random(seed + i); seed None only fills generators that do not exist yet."""
+        for i in range(self.num_envs):
+            if seed is not None:
+                self._rngs[i] = gym.np_random(int(seed) + i)[0]
+            elif self._rngs[i] is None:
+                self._rngs[i] = gym.np_random(None)[0]
+
+    def draw_spawn_nodes(self, mask: Optional[np.ndarray] = None) -> np.ndarray:
+        nodes = np.zeros(self.num_envs, dtype=np.int32)
+        for i in range(self.num_envs):
+            if mask is None or mask[i]:
+                nodes[i] = self.map.sample_spawn_node(self._rngs[i])
+        return nodes
+
+    def refill_spawn_queue(self) -> None:
+        """Pre-draws `spawn_queue_len` spawn nodes per env for device-side auto-reset (consumed cyclically)."""
+        q = np.zeros((self.num_envs, self.spawn_queue_len), dtype=np.int32)
+        for i in range(self.num_envs):
+            for j in range(self.spawn_queue_len):
+                q[i, j] = self.map.sample_spawn_node(self._rngs[i])
+        self._aux["spawn_queue"].copy_(torch.from_numpy(q))
+        self._aux["spawn_cursor"].zero_()
+
+    # ------------------------------------------------------------------ gym API
+    def reset(self, seed: Optional[int] = None, options: Optional[Any] = None, mask=None):
+        """env.py:101-113 for every env (or the envs selected by the boolean `mask`)."""
+        self.seed_generators(seed)
+        mk_np = None if mask is None else np.asarray(mask.cpu() if isinstance(mask, torch.Tensor) else mask).astype(bool)
+        nodes = self.draw_spawn_nodes(mk_np)
+        if self.autoreset and (seed is not None or not self._was_reset):
+            self.refill_spawn_queue()
+        self.reset_to(nodes, mk_np)
+        return self._obs(), self._info()
+
+    def reset_to(self, spawn_nodes, mask=None) -> None:
+        """Reset with explicit spawn nodes (lanepath node ids); device-side only, no RNG involved."""
+        nd = self._to_dev("spawn_nodes", spawn_nodes, torch.int32, (self.num_envs,))
+        mk = None if mask is None else self._to_dev("mask", np.asarray(mask, dtype=np.uint8), torch.uint8, (self.num_envs,))
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_reset(self._h, nd.data_ptr(), mk.data_ptr() if mk is not None else None,
+                                         self._flags() & ~nat.F_AUTORESET, self._stream()), "tc_reset")
+        self._keep = (nd, mk)
+        self._was_reset = True
+
+    def step(self, action: Dict[str, Any]):
+        """env.py:115-147 for every env.  action = {"car_control": [N,2] float32|float64, "maneuver": [N] int}."""
+        cc = action["car_control"]
+        if isinstance(cc, torch.Tensor):
+            dt = torch.float64 if cc.dtype == torch.float64 else torch.float32
+        else:
+            cc = np.asarray(cc)
+            dt = torch.float32 if cc.dtype == np.float32 else torch.float64
+        cc_t = self._to_dev("car_control", cc, dt, (self.num_envs, 2))
+        mn_t = self._to_dev("maneuver", action["maneuver"], torch.int32, (self.num_envs,))
+        self.step_device(cc_t, mn_t)
+        o = self.out
+        if self.return_numpy:
+            return (self._obs(), o["reward"].cpu().numpy(), o["terminated"].cpu().numpy().astype(bool),
+                    o["truncated"].cpu().numpy().astype(bool), self._info())
+        return self._obs(), o["reward"], o["terminated"].bool(), o["truncated"].bool(), self._info()
+
+    def step_device(self, car_control: torch.Tensor, maneuver: torch.Tensor) -> None:
+        """The bare hot path: one launch, nothing returned (results are in self.out / self.state)."""
+        if not self._was_reset:
+            raise RuntimeError("step() before reset()")
+        dt = nat.F64 if car_control.dtype == torch.float64 else nat.F32
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_step(self._h, car_control.data_ptr(), dt, maneuver.data_ptr(), self._flags(),
+                                        self._stream()), "tc_step")
+        self._keep = (car_control, maneuver)
+
+    def render(self):
+        """rgb_array of the class-agnostic camera view is only available in 'rgb' observation format."""
+        if self.render_mode == "rgb_array" and self._fmt == nat.FMT_RGB:
+            return self._obs()
+        return None
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            nat.lib().tc_env_destroy(self._h)
+            self._h = None
+            self._nmap.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ outputs
+    def _obs(self):
+        o = self.out["obs"]
+        if self.no_observation and self.render_mode is None:
+            o = torch.zeros_like(o)  # env.py:81
+        return o.cpu().numpy() if self.return_numpy else o
+
+    def _info(self) -> Dict[str, Any]:
+        """Batched version of env.py:83-85.  `local_path` is [N,4,2] (rows past `local_path_len` are 0)."""
+        st, o = self.state, self.out
+        valid = o["nearest_edge"][:, 0] >= 0                      # car.get_info returned real values
+        n = torch.where(valid, st["lp_len"], torch.zeros_like(st["lp_len"]))
+        idx = st["local_path"][:, 1::2].long().clamp(min=0)
+        coords = self._lp_nodes[idx]                              # nodes[edge[1]] per edge (car.py:66)
+        keep = (torch.arange(4, device=self.device)[None, :] < n[:, None])
+        coords = coords * keep[:, :, None]
+        info = {
+            "cte": o["cte"], "heading_error": o["heading_error"],
+            "position": torch.stack([st["x"], st["y"]], dim=1), "orientation": st["theta"],
+            "laneline_distances": {name: o["laneline_distances"][:, i] for i, name in enumerate(self.layer_names)},
+            "local_path": coords, "local_path_len": n,
+            "velocity": torch.where(valid, st["velocity"], torch.zeros_like(st["velocity"])),
+            "status": o["status"],
+        }
+        if self.return_numpy:
+            def cv(v):
+                return {k: cv(x) for k, x in v.items()} if isinstance(v, dict) else v.cpu().numpy()
+            info = {k: cv(v) for k, v in info.items()}
+        return info
