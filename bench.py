@@ -65,6 +65,23 @@ def gen_actions(n_envs, n_steps, seed, device):
     return cc, man
 
 
+def host_cores():
+    """Host threads this process may really use: cgroup cpu quota if there is one, else the affinity mask,
+    capped at 16 (the CPU share of a one-GPU box)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("TC_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(w, cfg, budget_env_steps):
     """The CPU oracle (oracle/tc_oracle.c, libm mode, OpenMP over envs) timed on this box's host cores on a
     bounded sample of the same workload: same map / resolution / format / action distribution."""
@@ -74,10 +91,7 @@ def cpu_baseline(w, cfg, budget_env_steps):
     from tinycarlo_amd.config import CarParams
     from tinycarlo_amd.map import Map
     from tinycarlo_amd import gym
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     m = Map(cfg["map"])
     car = CarParams.from_config(1 / cfg["sim"].get("fps", 30), cfg["car"])
     cam = Camera(cfg["camera"])
@@ -111,7 +125,7 @@ def main():
     ap.add_argument("--gather", default="flags", choices=["none", "flags", "obs"],
                     help="what is gathered to rank 0 over RCCL each step when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=int, default=200000, help="env-steps of the CPU baseline sample")
+    ap.add_argument("--cpu-budget", type=int, default=2000000, help="env-steps of the CPU baseline sample")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -482,16 +482,20 @@ __device__ inline void r_line2(const Ras& r, long long p1x, long long p1y, long 
   }
 }
 
-__device__ inline long long pick4(const long long* v, int i) {  // register-resident v[i]
-  long long r = v[0];
-  r = i == 1 ? v[1] : r;
-  r = i == 2 ? v[2] : r;
-  r = i == 3 ? v[3] : r;
+// The four polygon vertices travel as BY-VALUE scalars.  Any aggregate (array or struct behind a
+// reference) lets LLVM fold "select of loads" into "load of selected pointer", which pins the
+// aggregate in scratch memory -- and scratch write-back shows up as HBM traffic.
+__device__ inline long long sel4(long long a0, long long a1, long long a2, long long a3, int i) {
+  long long r = a0;
+  r = i == 1 ? a1 : r;
+  r = i == 2 ? a2 : r;
+  r = i == 3 ? a3 : r;
   return r;
 }
 
 // FillConvexPoly(v[4], shift = 16), LINE_8
-__device__ inline void r_fill_convex_poly4(const Ras& r, const long long* vx, const long long* vy) {
+__device__ inline void r_fill_convex_poly4(const Ras& r, long long qx0, long long qx1, long long qx2, long long qx3,
+                                           long long qy0, long long qy1, long long qy2, long long qy3) {
   const int npts = 4, shift = TC_XY_SHIFT;
   const int delta = 1 << shift >> 1;
   int e_idx[2], e_di[2], e_ye[2];
@@ -499,12 +503,12 @@ __device__ inline void r_fill_convex_poly4(const Ras& r, const long long* vx, co
   int imin = 0;
   int edges = npts;
   long long xmin, xmax, ymin, ymax;
-  long long p0x = vx[3], p0y = vy[3];
-  xmin = xmax = vx[0];
-  ymin = ymax = vy[0];
+  long long p0x = qx3, p0y = qy3;
+  xmin = xmax = qx0;
+  ymin = ymax = qy0;
 #pragma unroll
   for (int i = 0; i < npts; i++) {
-    long long px = vx[i], py = vy[i];
+    long long px = sel4(qx0, qx1, qx2, qx3, i), py = sel4(qy0, qy1, qy2, qy3, i);
     if (py < ymin) {
       ymin = py;
       imin = i;
@@ -542,9 +546,9 @@ __device__ inline void r_fill_convex_poly4(const Ras& r, const long long* vx, co
         int idx = idx0 + di;
         if (idx >= npts) idx -= npts;
         for (; edges-- > 0;) {
-          int ty = d_wrap32((pick4(vy, idx) + delta) >> shift);
+          int ty = d_wrap32((sel4(qy0, qy1, qy2, qy3, idx) + delta) >> shift);
           if (ty > y) {
-            long long xs = pick4(vx, idx0), xe = pick4(vx, idx);
+            long long xs = sel4(qx0, qx1, qx2, qx3, idx0), xe = sel4(qx0, qx1, qx2, qx3, idx);
             e_ye[i] = ty;
             e_dx[i] = ((xe - xs) * 2 + ((long long)ty - y)) / (2 * ((long long)ty - y));
             e_x[i] = xs;
@@ -636,9 +640,7 @@ __device__ inline void r_thick_line(const Ras& r, int x0, int y0, int x1, int y1
   if (tc_fabs(rr) > 2.2204460492503131e-16) {
     rr = ((double)th + odd * TC_XY_ONE * 0.5) / sqrt(rr);
     long long dpx = __double2int_rn(dy * rr), dpy = __double2int_rn(dx * rr);
-    long long vx[4] = {p0x + dpx, p0x - dpx, p1x - dpx, p1x + dpx};
-    long long vy[4] = {p0y + dpy, p0y - dpy, p1y - dpy, p1y + dpy};
-    r_fill_convex_poly4(r, vx, vy);
+    r_fill_convex_poly4(r, p0x + dpx, p0x - dpx, p1x - dpx, p1x + dpx, p0y + dpy, p0y - dpy, p1y - dpy, p1y + dpy);
   }
   int rad = (int)((th + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
   r_circle_fill(r, d_wrap32((p0x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), d_wrap32((p0y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), rad);

@@ -25,6 +25,12 @@
 #define MODE_RESET 1
 #define MODE_RENDER 2
 
+// ablation switches for profiling (not part of the ABI contract; results are wrong when set)
+#define DBG_SKIP_RASTER 0x100u
+#define DBG_SKIP_STORE 0x200u
+#define DBG_SKIP_CAMERA 0x400u
+#define DBG_SKIP_DIST 0x800u
+
 struct LdsLayout {
   int off_p, off_flg, off_list, off_seg, off_bits, off_cnt;
   int seg_cap;
@@ -216,11 +222,16 @@ __global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const 
       b.status[env] = status;
       if (b.needs_reset) b.needs_reset[env] = (flags & TC_F_AUTORESET) ? (unsigned char)(terminated || trunc) : 0;
     }
-    if (tid < 8) b.local_path[env * 8 + tid] = s.lp[tid];
+    if (tid < 8) {  // register-resident select (a runtime-indexed s.lp[tid] would live in scratch)
+      int v = s.lp[0];
+#pragma unroll
+      for (int i = 1; i < 8; i++) v = tid == i ? s.lp[i] : v;
+      b.local_path[env * 8 + tid] = v;
+    }
 
     // ---- phase B: lane-line distances (car.py:55-64)
     const int C = m.C;
-    if (have_info) {
+    if (have_info && !(flags & DBG_SKIP_DIST)) {
       for (int i = tid; i < m.total_nodes; i += TC_NT) {
         double2 n = m.nodes[i];
         dn[i] = d_dist(s.x, s.y, n.x, n.y);
@@ -269,6 +280,7 @@ __global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const 
 
   // ---- phase C: camera (camera.py:52-110) + raster (renderer.py:36-51)
   if ((flags & TC_F_NO_OBSERVATION) || b.obs == nullptr) return;
+  if (flags & DBG_SKIP_CAMERA) return;
   const DevCam& cam = a.cam;
   double pose[12];
   {
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const 
     const int nwords = C * cam.band_rows * wpr;
     for (int i = tid; i < nwords; i += TC_NT) bits[i] = 0;
     __syncthreads();
-    for (int k = tid; k < nseg; k += TC_NT) {
+    for (int k = tid; k < nseg && !(flags & DBG_SKIP_RASTER); k += TC_NT) {
       const int* sg = seg + 5 * k;
       Ras r;
       r.bits = bits + sg[0] * cam.band_rows * wpr;
@@ -354,7 +366,8 @@ __global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const 
       r_thick_line(r, sg[1], sg[2], sg[3], sg[4], cam.thickness);
     }
     __syncthreads();
-    if (cam.format == TC_FMT_CLASSES) {
+    if (flags & DBG_SKIP_STORE) {
+    } else if (cam.format == TC_FMT_CLASSES) {
       if ((W & 15) == 0) {
         // 16 pixels -> one 16-byte store per lane, consecutive lanes on consecutive addresses
         const int per_plane = rows * W / 16;

@@ -74,6 +74,7 @@ class TinyCarloVecEnv:
         self.render_mode = render_mode
         self.return_numpy = return_numpy
         self.autoreset = autoreset
+        self._debug_flags = int(os.environ.get("TC_DEBUG_FLAGS", "0"), 0)  # profiling ablations only
         self.wrapped = False          # env.py:56
         self.no_observation = False   # env.py:60
 
@@ -147,7 +148,7 @@ class TinyCarloVecEnv:
             f |= nat.F_WRAPPED
         if self.autoreset:
             f |= nat.F_AUTORESET
-        return f
+        return f | self._debug_flags
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
