@@ -1,0 +1,234 @@
+"""CPU tests of the host side (no GPU): the gym-facing env classes, seeding / spawn sampling, info dicts,
+wrappers.  The engine underneath is tests/oracle_backend.py (the CPU oracle) -- the shipped classes are
+exercised unchanged except for that injected engine."""
+import copy
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import orc
+from common import cam_keys, golden, load_cfg, map_of, rollout_files, RES
+from oracle_backend import OracleVecEnv
+from tinycarlo_amd import gym
+from tinycarlo_amd.config import bundled_config
+from tinycarlo_amd.env import TinyCarloEnv
+from tinycarlo_amd.wrapper import (CTELinearRewardWrapper, CTESparseRewardWrapper, CTETerminationWrapper,
+                                   CrashTerminationWrapper, LanelineCrossingTerminationWrapper,
+                                   LanelineLinearRewardWrapper, LanelineSparseRewardWrapper)
+from tinycarlo_amd.wrapper.utils import linear_reward, sparse_reward
+
+
+@pytest.fixture(autouse=True)
+def _inject(monkeypatch):
+    monkeypatch.setattr(TinyCarloEnv, "_vec_cls", OracleVecEnv)
+    orc.set_math_mode(orc.MATH_LIBM)
+
+
+def cfg_for(mp, rk="r64", fmt="classes"):
+    cfg, path = load_cfg(mp)
+    cfg = copy.deepcopy(cfg)
+    cfg["camera"]["resolution"] = list(RES[rk])
+    cfg["sim"]["observation_space_format"] = fmt
+    cfg["map"]["json_path"] = os.path.join(os.path.dirname(path), cfg["map"]["json_path"])
+    return cfg
+
+
+def test_make_and_random_control_loop():
+    """examples/random_control.py against the bundled yaml (BASELINE config 1 plumbing)."""
+    env = gym.make("tinycarlo-v2", config=bundled_config("config_simple_layout.yaml"))
+    assert env.observation_space.shape == (128, 160, 3) and env.observation_space.dtype == np.uint8  # yaml: rgb 128x160
+    env.action_space.seed(0)
+    obs, info = env.reset(seed=0)
+    assert obs.shape == (128, 160, 3) and obs.dtype == np.uint8 and obs.max() > 0
+    assert info["cte"] == 0 and info["local_path"] == [] and info["velocity"] == 0.0
+    assert set(info) == {"cte", "heading_error", "position", "orientation", "laneline_distances", "local_path", "velocity"}
+    assert list(info["laneline_distances"]) == ["outer", "dashed", "solid", "hold", "area"]
+    steps = 0
+    while steps < 50:
+        action = env.action_space.sample()
+        obs, reward, terminated, truncated, info = env.step(action)
+        assert isinstance(reward, float) and isinstance(terminated, bool) and isinstance(truncated, bool)
+        assert isinstance(info["cte"], float) and len(info["position"]) == 2
+        steps += 1
+        if terminated or truncated:
+            obs, info = env.reset()
+            break
+    env.close()
+
+
+def test_human_render_mode_rejected_and_config_required():
+    with pytest.raises(ValueError):
+        TinyCarloEnv(render_mode="human", config=cfg_for("simple_layout"))
+    with pytest.raises(ValueError):
+        TinyCarloEnv()
+
+
+@pytest.mark.parametrize("fname", [f for f in rollout_files() if "r480" not in f and "stanley_3" not in f])
+def test_env_reproduces_reference_rollout(fname):
+    """reset(seed) + step() through the public API reproduce the reference rollouts: same spawn nodes out of
+    the seeded np_random, same truncation/termination times, info within 1e-9, same local path."""
+    d = golden(fname)
+    mp = map_of(fname)
+    k = cam_keys(d)[0]
+    env = TinyCarloEnv(config=cfg_for(mp, k))
+    seed = int(d["seed"])
+    resets = {int(s): i for i, s in enumerate(d["reset_step"])}
+    obs, info = env.reset(seed=seed)
+    assert env.car.local_path[0][0] == int(d["reset_spawn_node"][0])
+    T = len(d["v"])
+    for t in range(T):
+        if t in resets and t > 0:
+            obs, info = env.reset()
+            assert env.car.local_path[0][0] == int(d["reset_spawn_node"][resets[t]]), t
+        obs, reward, term, trunc, info = env.step({"car_control": [d["v"][t], d["s"][t]], "maneuver": int(d["maneuver"][t])})
+        assert trunc == bool(d["truncated"][t]) and term == bool(d["terminated"][t]), t
+        assert abs(info["cte"] - d["cte"][t]) < 1e-9 and abs(info["heading_error"] - d["heading_error"][t]) < 1e-9
+        assert abs(reward - d["reward"][t]) < 1e-9
+        assert np.allclose(info["position"], [d["post_x"][t], d["post_y"][t]], atol=1e-9, rtol=0)
+        n = int(d["n_lp_coords"][t])
+        assert len(info["local_path"]) == n
+        if n:
+            assert np.allclose(np.array(info["local_path"]), d["lp_coords"][t][:n], atol=1e-12, rtol=0)
+        assert np.allclose([info["laneline_distances"][x] for x in env.vec.layer_names], d["dist"][t], atol=1e-9, rtol=0)
+    env.close()
+
+
+def test_vec_env_seeding_matches_single_envs():
+    """env i of a batch reset with seed s behaves like a single env reset with seed s+i."""
+    cfg = cfg_for("knuffingen", "r64")
+    vec = OracleVecEnv(cfg, num_envs=6)
+    obs, info = vec.reset(seed=10)
+    for i in range(6):
+        e = TinyCarloEnv(config=cfg)
+        e.reset(seed=10 + i)
+        assert e.car.local_path == [tuple(int(x) for x in vec.state["local_path"][i, :2])]
+        assert e.car.position == [float(vec.state["x"][i]), float(vec.state["y"][i])]
+    assert obs.shape == (6, 5, 64, 64) and obs.dtype == torch.uint8
+    assert info["local_path"].shape == (6, 4, 2) and int(info["local_path_len"].sum()) == 0
+    cc = np.tile(np.array([[0.8, 0.0]], dtype=np.float32), (6, 1))
+    obs, rew, term, trunc, info = vec.step({"car_control": cc, "maneuver": np.zeros(6, dtype=np.int32)})
+    assert rew.shape == (6,) and term.dtype == torch.bool and int(info["local_path_len"].min()) >= 1
+    assert set(info["laneline_distances"]) == set(vec.layer_names)
+    # masked reset only touches the selected envs
+    before = {k: v.clone() for k, v in vec.state.items()}
+    vec.reset(mask=np.array([1, 0, 0, 1, 0, 0], dtype=bool))
+    for i in (1, 2, 4, 5):
+        assert all(torch.equal(before[k][i], vec.state[k][i]) for k in before)
+    assert int(vec.state["lp_len"][0]) == 1 and int(vec.state["lp_len"][3]) == 1
+
+
+def test_autoreset_consumes_spawn_queue():
+    cfg = cfg_for("simple_layout", "r64")
+    vec = OracleVecEnv(cfg, num_envs=4, autoreset=True, spawn_queue_len=4)
+    vec.reset(seed=0)
+    q = vec._aux["spawn_queue"].clone()
+    vec._aux["needs_reset"][2] = 1
+    cc = np.tile(np.array([[0.8, 0.0]]), (4, 1))
+    obs, rew, term, trunc, info = vec.step({"car_control": cc, "maneuver": np.zeros(4, dtype=np.int32)})
+    assert int(vec.state["local_path"][2, 0]) == int(q[2, 0]) and int(vec.state["lp_len"][2]) == 1
+    assert int(vec._aux["spawn_cursor"][2]) == 1 and float(rew[2]) == 0.0 and int(info["local_path_len"][2]) == 0
+    assert int(vec.state["lp_len"][0]) == 4
+
+
+def test_no_observation_and_render():
+    cfg = cfg_for("simple_layout", "r64", "classes")
+    env = TinyCarloEnv(config=cfg, render_mode="rgb_array")
+    env.reset(seed=1)
+    frame = env.render()
+    assert frame.shape == (64, 64, 3) and frame.max() > 0  # rgb view although the observation is 'classes'
+    cols = {tuple(c) for c in frame.reshape(-1, 3)} - {(0, 0, 0)}
+    assert cols <= {tuple(c) for c in env.map.get_laneline_colors()}
+    env2 = TinyCarloEnv(config=cfg)
+    env2.no_observation = True
+    env2.reset(seed=1)
+    obs, *_ = env2.step({"car_control": [0.5, 0.0], "maneuver": 0})
+    assert obs.shape == (5, 64, 64) and obs.max() == 0  # env.py:81
+
+
+def test_camera_update_params_changes_frame():
+    env = TinyCarloEnv(config=cfg_for("simple_layout", "r64"))
+    obs0, _ = env.reset(seed=4)
+    env.unwrapped.camera.orientation = [35, 0, 0]   # train_stanley_il.py:55-57
+    env.unwrapped.camera.fov = 100
+    env.unwrapped.camera.update_params()
+    obs1, _ = env.reset(seed=4)
+    assert obs0.shape == obs1.shape and (obs0 != obs1).any()
+
+
+# ------------------------------------------------------------------ wrappers (wrapper/*.py of the reference)
+def test_reward_helpers_scalar_and_tensor():
+    assert linear_reward(0.0, 0.1) == 1.0 and linear_reward(0.05, 0.1) == pytest.approx(0.5) and linear_reward(0.2, 0.1) == 0.0
+    assert linear_reward(0.2, 0.1, max_reward=-1.0, min_reward=0.0) == 0.0 and linear_reward(0.05, 0.1, -1.0) == pytest.approx(-0.5)
+    x = torch.tensor([0.0, -0.05, 0.2], dtype=torch.float64)
+    assert torch.allclose(linear_reward(x, 0.1), torch.tensor([1.0, 0.5, 0.0], dtype=torch.float64))
+    assert sparse_reward({"a": True, "b": False, "c": True}, {"a": 1.0, "b": 5.0}) == 1.0
+    r = sparse_reward({"a": torch.tensor([True, False])}, {"a": 2.0})
+    assert r.tolist() == [2.0, 0.0]
+
+
+def _drive(env, n, batched):
+    out = []
+    for t in range(n):
+        if batched:
+            N = env.unwrapped.num_envs
+            a = {"car_control": np.tile([[0.7, 0.3 * math.sin(t / 5)]], (N, 1)), "maneuver": np.full(N, t // 20 % 4, dtype=np.int32)}
+        else:
+            a = {"car_control": [0.7, 0.3 * math.sin(t / 5)], "maneuver": t // 20 % 4}
+        out.append(env.step(a))
+    return out
+
+
+def test_wrappers_scalar_vs_batched_and_formulas():
+    cfg = cfg_for("simple_layout", "r64")
+
+    def wrap(e):
+        e = CTESparseRewardWrapper(e, 0.01)
+        e = CTELinearRewardWrapper(e, 0.05, max_reward=2.0)
+        e = LanelineLinearRewardWrapper(e, {"outer": -1.0, "dashed": -0.5, "solid": -1.0, "hold": 0.0, "area": 0.0})
+        e = LanelineSparseRewardWrapper(e, {"outer": -10.0})
+        e = LanelineCrossingTerminationWrapper(e, "outer")
+        e = CTETerminationWrapper(e, 0.02, number_of_steps=3)
+        e = CrashTerminationWrapper(e, 0.005, number_of_steps=4)
+        return e
+
+    single = wrap(TinyCarloEnv(config=cfg))
+    assert single.unwrapped.wrapped is True
+    single.reset(seed=5)
+    vec = wrap(OracleVecEnv(cfg, num_envs=3))
+    vec.reset(seed=5)  # env 0 == the single env
+    rs = _drive(single, 60, False)
+    rv = _drive(vec, 60, True)
+    tw = single.unwrapped.car.track_width
+    for (o1, r1, te1, tr1, i1), (o2, r2, te2, tr2, i2) in zip(rs, rv):
+        assert r1 == pytest.approx(float(r2[0]), abs=1e-12)
+        assert te1 == bool(te2[0]) and tr1 == bool(tr2[0])
+        # formulas of wrapper/reward.py on the info of the same step
+        exp = (1.0 if abs(i1["cte"]) <= 0.01 else 0.0) + max(-2.0 / 0.05 * abs(i1["cte"]) + 2.0, 0.0)
+        for name, mr in {"outer": -1.0, "dashed": -0.5, "solid": -1.0}.items():
+            exp += min(-mr / tw * abs(i1["laneline_distances"][name]) + mr, 0.0)
+        exp += -10.0 if i1["laneline_distances"]["outer"] < tw / 2 else 0.0
+        assert r1 == pytest.approx(exp, abs=1e-12)
+    assert any(te for _, _, te, _, _ in rs)  # the termination wrappers fired at least once on this drive
+
+
+def test_cte_termination_counter_semantics():
+    """termination.py:39-48: fires on the n-th consecutive violation, then restarts counting."""
+    class Fake(gym.Env):
+        wrapped = False
+        car = type("C", (), {"track_width": 0.03})()
+        def __init__(self, ctes): self.ctes = list(ctes)
+        def step(self, a): return None, 0.0, False, False, {"cte": self.ctes.pop(0), "velocity": 1.0}
+    w = CTETerminationWrapper(Fake([0.5, 0.5, 0.0, 0.5, 0.5, 0.5, 0.5]), 0.1, number_of_steps=3)
+    got = [w.step(None)[2] for _ in range(7)]
+    assert got == [False, False, False, False, False, True, False]
+    ten = lambda v: torch.tensor(v, dtype=torch.float64)
+    class FakeB(Fake):
+        def step(self, a):
+            c = self.ctes.pop(0)
+            return None, torch.zeros(2, dtype=torch.float64), torch.zeros(2, dtype=torch.bool), torch.zeros(2, dtype=torch.bool), {"cte": ten([c, 0.5]), "velocity": ten([1, 1])}
+    wb = CTETerminationWrapper(FakeB([0.5, 0.5, 0.0, 0.5, 0.5, 0.5, 0.5]), 0.1, number_of_steps=3)
+    gb = [wb.step(None)[2].tolist() for _ in range(7)]
+    assert [g[0] for g in gb] == got and [g[1] for g in gb] == [False, False, True, False, False, True, False]

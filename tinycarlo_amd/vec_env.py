@@ -48,7 +48,7 @@ class CarView:
         self.max_deceleration = p.max_deceleration
 
 
-class TinyCarloVecEnv:
+class TinyCarloVecEnv(gym.Env):
     metadata = {"render_modes": ["rgb_array"]}
 
     def __init__(self, config: Union[str, Dict[str, Any]], num_envs: Optional[int] = None,
@@ -66,10 +66,6 @@ class TinyCarloVecEnv:
             raise ValueError("num_envs must be >= 1")
         self.device = torch.device(device) if device is not None else (
             torch.device(sim["device"]) if "device" in sim else _default_device())
-        if self.device.type != "cuda":
-            raise nat.NativeError("tinycarlo_amd runs on an AMD GPU (device 'cuda:N' under ROCm); there is no CPU path")
-        if not torch.cuda.is_available():
-            raise nat.NativeError("no GPU visible to torch: tinycarlo_amd has no CPU fallback")
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         self.render_mode = render_mode
         self.return_numpy = return_numpy
@@ -96,7 +92,20 @@ class TinyCarloVecEnv:
         self.action_space = self.single_action_space
         self.observation_space = self.single_observation_space
 
+        self.spawn_queue_len = int(spawn_queue_len)
+        self._obs_shape = obs_shape
+        self._setup_device()
+        self._rngs: List[Optional[np.random.Generator]] = [None] * self.num_envs
+        self._was_reset = False
+
+    def _setup_device(self) -> None:
+        """Creates the native handles and the device tensors the HIP library works on (no CPU path)."""
+        if self.device.type != "cuda":
+            raise nat.NativeError("tinycarlo_amd runs on an AMD GPU (device 'cuda:N' under ROCm); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise nat.NativeError("no GPU visible to torch: tinycarlo_amd has no CPU fallback")
         L = nat.lib()
+        obs_shape = self._obs_shape
         N, Cn, dev = self.num_envs, self.n_classes, self.device
         with torch.cuda.device(dev):
             self._nmap = nat.NativeMap(self.map)
@@ -119,7 +128,6 @@ class TinyCarloVecEnv:
                 "terminated": torch.zeros(N, **u8), "truncated": torch.zeros(N, **u8), "status": torch.zeros(N, **i32),
                 "laneline_distances": torch.zeros((N, Cn), **f64), "nearest_edge": torch.full((N, Cn), -1, **i32),
                 "obs": torch.zeros((N,) + obs_shape, **u8)}
-            self.spawn_queue_len = int(spawn_queue_len)
             self._aux: Dict[str, torch.Tensor] = {
                 "needs_reset": torch.zeros(N, **u8), "spawn_queue": torch.zeros((N, self.spawn_queue_len), **i32),
                 "spawn_cursor": torch.zeros(N, **i32)}
@@ -131,9 +139,6 @@ class TinyCarloVecEnv:
             nat.check(L.tc_env_bind(self._h, C.byref(b)), "tc_env_bind")
         self.obs_bytes_per_env = int(L.tc_env_obs_bytes(self._h))
         self.lds_bytes = int(L.tc_env_lds_bytes(self._h))
-        self._rngs: List[Optional[np.random.Generator]] = [None] * N
-        self._action_bufs: Dict[Any, torch.Tensor] = {}
-        self._was_reset = False
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -239,6 +244,11 @@ class TinyCarloVecEnv:
             nat.check(nat.lib().tc_step(self._h, car_control.data_ptr(), dt, maneuver.data_ptr(), self._flags(),
                                         self._stream()), "tc_step")
         self._keep = (car_control, maneuver)
+
+    def render_current(self) -> None:
+        """Camera.capture_frame of the current state into self.out["obs"], no step (camera.py:52)."""
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_render(self._h, 0, self._stream()), "tc_render")
 
     def render(self):
         """rgb_array of the class-agnostic camera view is only available in 'rgb' observation format."""

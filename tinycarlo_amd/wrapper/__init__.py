@@ -1,0 +1,3 @@
+from .reward import (CTELinearRewardWrapper, CTESparseRewardWrapper, LanelineLinearRewardWrapper,  # noqa: F401
+                     LanelineSparseRewardWrapper)
+from .termination import CrashTerminationWrapper, CTETerminationWrapper, LanelineCrossingTerminationWrapper  # noqa: F401
