@@ -27,6 +27,8 @@ struct DevMap {
   int max_nodes, max_edges, total_nodes, total_edges;
   const double2* nodes;   // lane-line nodes, all layers concatenated
   const int2* edges;      // lane-line edges (layer-local node ids)
+  const int2* edges_g;    // the same edges with global node ids (node_off[layer] + local id)
+  const int* edge_layer;  // layer of each edge
   const double* ori_fwd;  // per lane-line edge: atan2(evy, evx)
   const double* ori_rev;  // per lane-line edge: atan2(-evy, -evx)
   unsigned char colors[16][3];
@@ -328,24 +330,37 @@ struct Ras {
 
 __device__ inline int d_wrap32(long long v) { return (int)(unsigned int)(unsigned long long)v; }
 
+// Branch-free on purpose: divergent `if`s inside the pixel loops cost more exec-mask bookkeeping than the
+// work they skip; an out-of-window pixel ORs 0 into word 0 of the plane instead.
 __device__ inline void r_put(const Ras& r, int x, int y) {
-  if ((unsigned)x >= (unsigned)r.W || y < r.y0 || y >= r.y1) return;
-  atomicOr(&r.bits[(y - r.y0) * r.wpr + (x >> 5)], 1u << (x & 31));
+  const bool ok = (unsigned)x < (unsigned)r.W && (unsigned)(y - r.y0) < (unsigned)(r.y1 - r.y0);
+  const int idx = ok ? (y - r.y0) * r.wpr + (x >> 5) : 0;
+  atomicOr(&r.bits[idx], ok ? 1u << (x & 31) : 0u);
 }
 
-// inclusive span [xl, xr] on row y
+// inclusive span [xl, xr] on row y, clamped to the image and the band
 __device__ inline void r_hline(const Ras& r, int y, int xl, int xr) {
-  if (y < r.y0 || y >= r.y1) return;
-  if (xl < 0) xl = 0;
-  if (xr > r.W - 1) xr = r.W - 1;
-  if (xl > xr) return;
-  unsigned int* row = r.bits + (y - r.y0) * r.wpr;
-  int w0 = xl >> 5, w1 = xr >> 5;
+  xl = xl < 0 ? 0 : xl;
+  xr = xr > r.W - 1 ? r.W - 1 : xr;
+  const bool ok = (unsigned)(y - r.y0) < (unsigned)(r.y1 - r.y0) && xl <= xr;
+  const int w0 = xl >> 5;
+  const int w1 = ok ? xr >> 5 : w0 - 1;
+  unsigned int* row = r.bits + (ok ? (y - r.y0) * r.wpr : 0);
   for (int w = w0; w <= w1; w++) {
-    unsigned int mk = 0xffffffffu;
-    if (w == w0) mk &= 0xffffffffu << (xl & 31);
-    if (w == w1) mk &= 0xffffffffu >> (31 - (xr & 31));
-    atomicOr(&row[w], mk);
+    const int lo = w == w0 ? (xl & 31) : 0;
+    const int hi = w == w1 ? (xr & 31) : 31;
+    atomicOr(&row[w], (0xffffffffu << lo) & (0xffffffffu >> (31 - hi)));
+  }
+}
+
+// Filled circle (round cap) from its per-row half widths hw[|dy|], dy = -rad..rad: the pixel set of
+// Circle(center, rad, fill) is the union of centred spans, so per row only the widest one matters.
+__device__ inline void r_cap(const Ras& r, int cx, int cy, int rad, const unsigned char* hw) {
+  for (int dy = -rad; dy <= rad; dy++) {
+    const int h = hw[dy < 0 ? -dy : dy];
+    long long y = (long long)cy + dy, xl = (long long)cx - h, xr = (long long)cx + h;
+    const bool ok = y >= 0 && y < r.H && xr >= 0 && xl < r.W;
+    r_hline(r, ok ? (int)y : -1, ok ? (int)(xl < 0 ? 0 : xl) : 1, ok ? (int)(xr > r.W - 1 ? r.W - 1 : xr) : 0);
   }
 }
 
@@ -430,6 +445,90 @@ __device__ inline void r_line_bresenham(const Ras& r, long long x1, long long y1
   }
 }
 
+// Truncating int64 division n / d (C semantics) through one correctly rounded f64 division when both
+// operands are below 2^52 (always the case after clipping); ~3x cheaper than the 64-bit integer
+// division sequence and exact: RN(n/d) can only overshoot floor(n/d) by one, which the remainder test undoes.
+__device__ inline long long d_sdiv(long long n, long long d) {
+  long long an = n < 0 ? -n : n, ad = d < 0 ? -d : d;
+  if (an < (1LL << 52) && ad < (1LL << 52)) {
+    long long q = (long long)((double)an / (double)ad);
+    if (an - q * ad < 0) q--;
+    return ((n < 0) != (d < 0)) ? -q : q;
+  }
+  return n / d;
+}
+
+// One polygon-outline edge after clipping, ready for random access by step index k (0..ecount):
+//   x-major: pixel (a + k, (b + k*step) >> 16)        y-major: pixel ((b + k*step) >> 16, a + k)
+// plus the far end point pixel (ex, ey) that Line2 writes first.
+struct LineP {
+  int a, b, step;
+  int ecount;  // -1: edge invisible
+  int ex, ey;
+  int xmajor;
+};
+
+__device__ inline LineP r_line2_setup(int W, int H, long long p1x, long long p1y, long long p2x, long long p2y) {
+  LineP L;
+  L.a = L.b = L.step = 0;
+  L.ecount = -1;
+  L.ex = L.ey = -1;
+  L.xmajor = 0;
+  if (!r_clip_line((long long)W << TC_XY_SHIFT, (long long)H << TC_XY_SHIFT, p1x, p1y, p2x, p2y)) return L;
+  long long dx = p2x - p1x, dy = p2y - p1y;
+  long long j = dx < 0 ? -1 : 0;
+  long long ax = (dx ^ j) - j;
+  long long i = dy < 0 ? -1 : 0;
+  long long ay = (dy ^ i) - i;
+  bool xmajor = ax > ay;
+  long long step;
+  if (xmajor) {
+    dy = (dy ^ j) - j;
+    if (j) {
+      long long t = p1x; p1x = p2x; p2x = t;
+      t = p1y; p1y = p2y; p2y = t;
+    }
+    step = d_sdiv(dy * TC_XY_ONE, ax | 1);
+    L.ecount = (int)((p2x - p1x) >> TC_XY_SHIFT);
+  } else {
+    dx = (dx ^ i) - i;
+    if (i) {
+      long long t = p1x; p1x = p2x; p2x = t;
+      t = p1y; p1y = p2y; p2y = t;
+    }
+    step = d_sdiv(dx * TC_XY_ONE, ay | 1);
+    L.ecount = (int)((p2y - p1y) >> TC_XY_SHIFT);
+  }
+  p1x += (TC_XY_ONE >> 1);
+  p1y += (TC_XY_ONE >> 1);
+  L.ex = (int)((p2x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
+  L.ey = (int)((p2y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
+  L.xmajor = xmajor;
+  L.step = (int)step;
+  if (xmajor) {
+    L.a = (int)(p1x >> TC_XY_SHIFT);
+    L.b = (int)p1y;
+  } else {
+    L.a = (int)(p1y >> TC_XY_SHIFT);
+    L.b = (int)p1x;
+  }
+  return L;
+}
+
+// steps k0..k1 (inclusive) of an outline edge
+__device__ inline void r_line2_pixels(const Ras& r, int a, int b, int step, int xmajor, int k0, int k1) {
+  int major = a + k0;
+  int minor = b + k0 * step;
+  for (int k = k0; k <= k1; k++) {
+    if (xmajor)
+      r_put(r, major, minor >> TC_XY_SHIFT);
+    else
+      r_put(r, minor >> TC_XY_SHIFT, major);
+    major++;
+    minor += step;
+  }
+}
+
 // Line2(): 16.16 fixed-point DDA (polygon outline)
 __device__ inline void r_line2(const Ras& r, long long p1x, long long p1y, long long p2x, long long p2y) {
   if (!r_clip_line((long long)r.W << TC_XY_SHIFT, (long long)r.H << TC_XY_SHIFT, p1x, p1y, p2x, p2y)) return;
@@ -448,7 +547,7 @@ __device__ inline void r_line2(const Ras& r, long long p1x, long long p1y, long 
       t = p1y; p1y = p2y; p2y = t;
     }
     x_step = TC_XY_ONE;
-    y_step = (dy * TC_XY_ONE) / (ax | 1);
+    y_step = d_sdiv(dy * TC_XY_ONE, ax | 1);
     ecount = (int)((p2x - p1x) >> TC_XY_SHIFT);
   } else {
     dx = (dx ^ i) - i;
@@ -456,7 +555,7 @@ __device__ inline void r_line2(const Ras& r, long long p1x, long long p1y, long 
       long long t = p1x; p1x = p2x; p2x = t;
       t = p1y; p1y = p2y; p2y = t;
     }
-    x_step = (dx * TC_XY_ONE) / (ay | 1);
+    x_step = d_sdiv(dx * TC_XY_ONE, ay | 1);
     y_step = TC_XY_ONE;
     ecount = (int)((p2y - p1y) >> TC_XY_SHIFT);
   }
@@ -493,9 +592,11 @@ __device__ inline long long sel4(long long a0, long long a1, long long a2, long 
   return r;
 }
 
-// FillConvexPoly(v[4], shift = 16), LINE_8
-__device__ inline void r_fill_convex_poly4(const Ras& r, long long qx0, long long qx1, long long qx2, long long qx3,
-                                           long long qy0, long long qy1, long long qy2, long long qy3) {
+// FillConvexPoly(v[4], shift = 16), LINE_8 -- the scanline part, restricted to rows [row_lo, row_hi).
+// Rows before the window are walked in closed form (OpenCV walks every row, also the negative ones, but
+// nothing except x += dx happens on a row that is not drawn), rows after it cannot matter.
+__device__ inline void r_fill_rows(const Ras& r, long long qx0, long long qx1, long long qx2, long long qx3,
+                                   long long qy0, long long qy1, long long qy2, long long qy3, int row_lo, int row_hi) {
   const int npts = 4, shift = TC_XY_SHIFT;
   const int delta = 1 << shift >> 1;
   int e_idx[2], e_di[2], e_ye[2];
@@ -503,7 +604,6 @@ __device__ inline void r_fill_convex_poly4(const Ras& r, long long qx0, long lon
   int imin = 0;
   int edges = npts;
   long long xmin, xmax, ymin, ymax;
-  long long p0x = qx3, p0y = qy3;
   xmin = xmax = qx0;
   ymin = ymax = qy0;
 #pragma unroll
@@ -516,9 +616,6 @@ __device__ inline void r_fill_convex_poly4(const Ras& r, long long qx0, long lon
     if (py > ymax) ymax = py;
     if (px > xmax) xmax = px;
     if (px < xmin) xmin = px;
-    r_line2(r, p0x, p0y, px, py);
-    p0x = px;
-    p0y = py;
   }
   xmin = (xmin + delta) >> shift;
   xmax = (xmax + delta) >> shift;
@@ -533,10 +630,8 @@ __device__ inline void r_fill_convex_poly4(const Ras& r, long long qx0, long lon
   e_di[1] = npts - 1;
   e_x[0] = e_x[1] = -TC_XY_ONE;
   e_dx[0] = e_dx[1] = 0;
-  // rows below draw_lo are walked in closed form (OpenCV walks negative rows one at a time; rows
-  // above the current band are handled identically: nothing but x += dx happens there)
-  const int draw_lo = r.y0 > 0 ? r.y0 : 0;
-  const int last = (int)ymax < r.y1 - 1 ? (int)ymax : r.y1 - 1;  // rows past the band end cannot matter
+  const int draw_lo = row_lo > 0 ? row_lo : 0;
+  const int last = (int)ymax < row_hi - 1 ? (int)ymax : row_hi - 1;
   if (y > last) return;
   do {
 #pragma unroll
@@ -550,7 +645,7 @@ __device__ inline void r_fill_convex_poly4(const Ras& r, long long qx0, long lon
           if (ty > y) {
             long long xs = sel4(qx0, qx1, qx2, qx3, idx0), xe = sel4(qx0, qx1, qx2, qx3, idx);
             e_ye[i] = ty;
-            e_dx[i] = ((xe - xs) * 2 + ((long long)ty - y)) / (2 * ((long long)ty - y));
+            e_dx[i] = d_sdiv((xe - xs) * 2 + ((long long)ty - y), 2 * ((long long)ty - y));
             e_x[i] = xs;
             e_idx[i] = idx;
             break;
@@ -588,6 +683,38 @@ __device__ inline void r_fill_convex_poly4(const Ras& r, long long qx0, long lon
   } while (++y <= last);
 }
 
+// rows of the image a FillConvexPoly of this quad can touch: [lo, hi], empty when lo > hi
+__device__ inline void r_fill_row_range(int W, int H, long long qx0, long long qx1, long long qx2, long long qx3,
+                                        long long qy0, long long qy1, long long qy2, long long qy3, int& lo, int& hi) {
+  const int delta = TC_XY_ONE >> 1;
+  long long xmin = qx0, xmax = qx0, ymin = qy0, ymax = qy0;
+  xmin = qx1 < xmin ? qx1 : xmin; xmin = qx2 < xmin ? qx2 : xmin; xmin = qx3 < xmin ? qx3 : xmin;
+  xmax = qx1 > xmax ? qx1 : xmax; xmax = qx2 > xmax ? qx2 : xmax; xmax = qx3 > xmax ? qx3 : xmax;
+  ymin = qy1 < ymin ? qy1 : ymin; ymin = qy2 < ymin ? qy2 : ymin; ymin = qy3 < ymin ? qy3 : ymin;
+  ymax = qy1 > ymax ? qy1 : ymax; ymax = qy2 > ymax ? qy2 : ymax; ymax = qy3 > ymax ? qy3 : ymax;
+  xmin = (xmin + delta) >> TC_XY_SHIFT;
+  xmax = (xmax + delta) >> TC_XY_SHIFT;
+  ymin = (ymin + delta) >> TC_XY_SHIFT;
+  ymax = (ymax + delta) >> TC_XY_SHIFT;
+  lo = 0;
+  hi = -1;
+  if (d_wrap32(xmax) < 0 || d_wrap32(ymax) < 0 || d_wrap32(xmin) >= W || d_wrap32(ymin) >= H) return;
+  if (ymax > H - 1) ymax = H - 1;
+  int y = d_wrap32(ymin);
+  lo = y > 0 ? y : 0;
+  hi = (int)ymax;
+}
+
+// FillConvexPoly = outline (4 x Line2) + scanline fill
+__device__ inline void r_fill_convex_poly4(const Ras& r, long long qx0, long long qx1, long long qx2, long long qx3,
+                                           long long qy0, long long qy1, long long qy2, long long qy3) {
+  r_line2(r, qx3, qy3, qx0, qy0);
+  r_line2(r, qx0, qy0, qx1, qy1);
+  r_line2(r, qx1, qy1, qx2, qy2);
+  r_line2(r, qx2, qy2, qx3, qy3);
+  r_fill_rows(r, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, r.y0, r.y1);
+}
+
 // Circle(center, radius, fill)
 __device__ inline void r_circle_fill(const Ras& r, int cx, int cy, int radius) {
   int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
@@ -621,6 +748,25 @@ __device__ inline void r_circle_fill(const Ras& r, int cx, int cy, int radius) {
     dx += mask;
     minus -= mask & 2;
   }
+}
+
+// ThickLine's quad for thickness > 1: returns false when the segment is degenerate (|r| <= DBL_EPSILON)
+__device__ inline bool r_quad(int x0, int y0, int x1, int y1, int thickness, long long& qx0, long long& qx1,
+                              long long& qx2, long long& qx3, long long& qy0, long long& qy1, long long& qy2,
+                              long long& qy3) {
+  long long p0x = (long long)x0 * TC_XY_ONE, p0y = (long long)y0 * TC_XY_ONE;
+  long long p1x = (long long)x1 * TC_XY_ONE, p1y = (long long)y1 * TC_XY_ONE;
+  const double INV_XY_ONE = 1. / TC_XY_ONE;
+  double dx = (double)(p0x - p1x) * INV_XY_ONE, dy = (double)(p1y - p0y) * INV_XY_ONE;
+  double rr = dx * dx + dy * dy;
+  int odd = thickness & 1;
+  long long th = (long long)thickness << (TC_XY_SHIFT - 1);
+  if (!(tc_fabs(rr) > 2.2204460492503131e-16)) return false;
+  rr = ((double)th + odd * TC_XY_ONE * 0.5) / sqrt(rr);
+  long long dpx = __double2int_rn(dy * rr), dpy = __double2int_rn(dx * rr);
+  qx0 = p0x + dpx; qx1 = p0x - dpx; qx2 = p1x - dpx; qx3 = p1x + dpx;
+  qy0 = p0y + dpy; qy1 = p0y - dpy; qy2 = p1y - dpy; qy3 = p1y + dpy;
+  return true;
 }
 
 // PolyLine(open, 2 points) -> ThickLine(p0, p1, thickness, LINE_8, flags = 3, shift = 0)

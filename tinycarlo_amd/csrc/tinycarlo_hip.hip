@@ -30,6 +30,13 @@
 #define DBG_SKIP_STORE 0x200u
 #define DBG_SKIP_CAMERA 0x400u
 #define DBG_SKIP_DIST 0x800u
+#define DBG_SKIP_R2 0x1000u
+#define DBG_SKIP_R3 0x2000u
+#define DBG_SKIP_R4 0x4000u
+
+#define RB 32        // segments rasterised per batch
+#define LCH 8        // outline steps per chunk
+#define FCH 8        // fill rows per chunk
 
 struct LdsLayout {
   int off_p, off_flg, off_list, off_seg, off_bits, off_cnt;
@@ -44,6 +51,9 @@ struct KArgs {
   tc_buffers b;
   LdsLayout lds;
   int N;
+  int* seg_g;  // [N][seg_cap][5] draw list of the current frame (library owned)
+  int* seg_n;  // [N]
+  int seg_cap;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -54,9 +64,7 @@ struct KArgs {
 // index by the lane that owns the chain's first edge.
 __device__ inline void cam_fixup_pass(double* Px, double* Py, double* Pz, unsigned char* flg, int bit, const int2* LE,
                                       int ne, bool target_e0, double tz, int* list, int* cnt) {
-  const int tid = threadIdx.x;
-  if (tid == 0) *cnt = 0;
-  __syncthreads();
+  const int tid = threadIdx.x;  // *cnt was zeroed (and a barrier passed) before the call
   for (int e = tid; e < ne; e += TC_NT) {
     int2 ed = LE[e];
     bool fa = flg[ed.x] & bit, fb = flg[ed.y] & bit;
@@ -117,11 +125,34 @@ __device__ inline int checked_spawn(const DevMap& m, int node, int& status) {
   return m.first_spawnable;
 }
 
-__device__ inline unsigned int spread4(unsigned int x) {  // 4 bits -> 4 bytes of 0x00/0xFF
-  return ((x & 1u) | ((x & 2u) << 7) | ((x & 4u) << 14) | ((x & 8u) << 21)) * 255u;
+__device__ inline unsigned int spread4(unsigned int x) {  // x < 16: 4 bits -> 4 bytes of 0x00/0xFF
+  return ((x * 0x00204081u) & 0x01010101u) * 255u;
 }
 
-__global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const void* car_control, int cdtype,
+// camera.py:133-142 for one node + the np.int32 cast of renderer.py:43,50
+__device__ inline int2 cam_project(const DevCam& cam, double X, double Y, double Z, double& u, double& v) {
+  double P3[3] = {X, Y, Z};
+  double h[3];
+  d_matmul<3, 3, 1>(cam.K, P3, h);
+  u = h[0] / h[2];
+  v = h[1] / h[2];
+  return make_int2(d_np_int32(u), d_np_int32(v));
+}
+
+__device__ inline int wave_incl_scan(int v) {
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int off = 1; off < TC_NT; off <<= 1) {
+    int o = __shfl_up(v, off);
+    if (lane >= off) v += o;
+  }
+  return v;
+}
+
+#ifndef TC_MIN_WAVES
+#define TC_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, int mode, const void* car_control, int cdtype,
                                                        const int* maneuver, const int* spawn_nodes,
                                                        const unsigned char* mask, unsigned int flags) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -133,13 +164,11 @@ __global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const 
   const DevMap& m = a.m;
   const tc_buffers& b = a.b;
   double* Px = (double*)(smem + a.lds.off_p);
-  double* Py = Px + m.max_nodes;
-  double* Pz = Py + m.max_nodes;
+  double* Py = Px + m.total_nodes;
+  double* Pz = Py + m.total_nodes;
   double* dn = Px;  // phase B alias
   unsigned char* flg = smem + a.lds.off_flg;
   int* list = (int*)(smem + a.lds.off_list);
-  int* seg = (int*)(smem + a.lds.off_seg);
-  unsigned int* bits = (unsigned int*)(smem + a.lds.off_bits);
   int* cnt = (int*)(smem + a.lds.off_cnt);
 
   // ---- state (wave-uniform loads)
@@ -291,62 +320,112 @@ __global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const 
     d_matmul<4, 4, 4>(R, Tm, car3d);
     d_matmul<3, 4, 4>(cam.E, car3d, pose);  // camera.py:62
   }
-  int* seg_cnt = cnt + 1;
-  if (tid == 0) *seg_cnt = 0;
-  for (int l = 0; l < m.C; l++) {
-    const int no = m.node_off[l], nn = m.node_off[l + 1] - no;
-    const int eo = m.edge_off[l], ne = m.edge_off[l + 1] - eo;
-    const int2* LE = m.edges + eo;
-    for (int i = tid; i < nn; i += TC_NT) {  // camera.py:124-131
-      double2 n = m.nodes[no + i];
-      double h[4] = {n.x, n.y, 0.0, 1.0};
-      double p[3];
-      d_matmul<3, 4, 1>(pose, h, p);
-      Px[i] = p[0];
-      Py[i] = p[1];
-      Pz[i] = p[2];
-      flg[i] = p[2] < 0 ? 1 : 0;  // camera.py:70
-    }
-    __syncthreads();
-    cam_fixup_pass(Px, Py, Pz, flg, 1, LE, ne, true, -0.0000001, list, cnt);   // camera.py:71-74
-    cam_fixup_pass(Px, Py, Pz, flg, 1, LE, ne, false, -0.0000001, list, cnt);  // camera.py:75-77
-    for (int i = tid; i < nn; i += TC_NT)
-      if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
-    __syncthreads();
-    cam_fixup_pass(Px, Py, Pz, flg, 2, LE, ne, true, -cam.max_range, list, cnt);   // camera.py:81-83
-    cam_fixup_pass(Px, Py, Pz, flg, 2, LE, ne, false, -cam.max_range, list, cnt);  // camera.py:84-86
-    for (int i = tid; i < nn; i += TC_NT) {  // camera.py:133-142, 90-93
-      double P3[3] = {Px[i], Py[i], Pz[i]};
-      double h[3];
-      d_matmul<3, 3, 1>(cam.K, P3, h);
-      double u = h[0] / h[2], v = h[1] / h[2];
-      bool vis = (u > 0) && (u < cam.W) && (v > 0) && (v < cam.H) && ((flg[i] & 3) == 3);
-      ((int2*)Px)[i] = make_int2(d_np_int32(u), d_np_int32(v));  // renderer.py:43,50 np.int32(...)
-      flg[i] = vis ? 4 : 0;
-    }
-    __syncthreads();
-    for (int e = tid; e < ne; e += TC_NT) {  // camera.py:95
-      int2 ed = LE[e];
-      if ((flg[ed.x] | flg[ed.y]) & 4) {
-        int k = atomicAdd(seg_cnt, 1);
-        if (k < a.lds.seg_cap) {
-          int2 pa = ((int2*)Px)[ed.x], pb = ((int2*)Px)[ed.y];
-          int* o = seg + 5 * k;
-          o[0] = l;
-          o[1] = pa.x;
-          o[2] = pa.y;
-          o[3] = pb.x;
-          o[4] = pb.y;
-        }
-      }
-    }
-    __syncthreads();
+  // All lane-line layers are processed together: node ids are made global (edges_g), so each of the
+  // passes below is ONE loop over all nodes / edges instead of one per layer (the layers never share
+  // nodes, so camera.py's per-layer loop and this are the same computation).
+  // counters: cnt[0..3] fix-up passes, cnt[4] projection candidates, cnt[5] draw list
+  int* seg_cnt = cnt + 5;
+  int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;  // [seg_cap][5]: layer, x0, y0, x1, y1
+  if (tid < 6) cnt[tid] = 0;
+  const int nn = m.total_nodes, ne = m.total_edges;
+  const int2* LE = m.edges_g;
+  for (int i = tid; i < nn; i += TC_NT) {  // camera.py:124-131
+    double2 n = m.nodes[i];
+    double h[4] = {n.x, n.y, 0.0, 1.0};
+    double p[3];
+    d_matmul<3, 4, 1>(pose, h, p);
+    Px[i] = p[0];
+    Py[i] = p[1];
+    Pz[i] = p[2];
+    flg[i] = p[2] < 0 ? 1 : 0;  // camera.py:70
   }
-  int nseg = *seg_cnt;
-  if (nseg > a.lds.seg_cap) nseg = a.lds.seg_cap;  // cannot happen: seg_cap == total edge count
+  __syncthreads();
+  cam_fixup_pass(Px, Py, Pz, flg, 1, LE, ne, true, -0.0000001, list, cnt + 0);   // camera.py:71-74
+  cam_fixup_pass(Px, Py, Pz, flg, 1, LE, ne, false, -0.0000001, list, cnt + 1);  // camera.py:75-77
+  for (int i = tid; i < nn; i += TC_NT)
+    if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
+  __syncthreads();
+  cam_fixup_pass(Px, Py, Pz, flg, 2, LE, ne, true, -cam.max_range, list, cnt + 2);   // camera.py:81-83
+  cam_fixup_pass(Px, Py, Pz, flg, 2, LE, ne, false, -cam.max_range, list, cnt + 3);  // camera.py:84-86
+  // Only nodes in front AND in range can be "visible" (camera.py:92-93): compact them so the two f64
+  // divisions of the projection are paid for those nodes only.
+  for (int i = tid; i < nn; i += TC_NT)
+    if ((flg[i] & 3) == 3) list[atomicAdd(cnt + 4, 1)] = i;
+  __syncthreads();
+  const int ncand = cnt[4];
+  for (int k = tid; k < ncand; k += TC_NT) {  // camera.py:133-142, 90
+    const int i = list[k];
+    double u, v;
+    int2 q = cam_project(cam, Px[i], Py[i], Pz[i], u, v);
+    bool vis = (u > 0) && (u < cam.W) && (v > 0) && (v < cam.H);
+    ((int2*)Px)[i] = q;  // renderer.py:43,50 np.int32(...)
+    flg[i] |= vis ? (4 | 8) : 8;  // 8: slot Px[i] now holds the int32 pixel coordinates
+  }
+  __syncthreads();
+  for (int e = tid; e < ne; e += TC_NT) {  // camera.py:95
+    int2 ed = LE[e];
+    const int fa = flg[ed.x], fb = flg[ed.y];
+    if ((fa | fb) & 4) {
+      double u, v;
+      int2 pa = (fa & 8) ? ((int2*)Px)[ed.x] : cam_project(cam, Px[ed.x], Py[ed.x], Pz[ed.x], u, v);
+      int2 pb = (fb & 8) ? ((int2*)Px)[ed.y] : cam_project(cam, Px[ed.y], Py[ed.y], Pz[ed.y], u, v);
+      int k = atomicAdd(seg_cnt, 1);
+      int* o = segg + 5 * k;  // k < seg_cap == total edge count
+      o[0] = m.edge_layer[e];
+      o[1] = pa.x;
+      o[2] = pa.y;
+      o[3] = pb.x;
+      o[4] = pb.y;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) a.seg_n[env] = *seg_cnt;  // handed to tc_raster_kernel through global memory
+}
 
-  const int H = cam.H, W = cam.W, wpr = cam.wpr, C = m.C;
-  unsigned char* out = b.obs + (size_t)env * ((size_t)H * W * (cam.format == TC_FMT_CLASSES ? C : 3));
+// ---------------------------------------------------------------------------------------------
+// Kernel 2: renderer.py:36-51 -- cv2.polylines of every segment into LDS bit-planes, then the frame is
+// written to HBM once with 16-byte stores.  One wavefront per env; small argument block, small LDS.
+struct RCam {
+  int H, W, wpr, band_rows, n_bands, thickness, format;
+  int cap_r;                  // round-cap radius of ThickLine: (thickness*32768 + 32768) >> 16
+  unsigned char cap_hw[32];   // half width of the cap per |row offset| (midpoint circle of drawing.cpp)
+};
+struct RArgs {
+  int N, C;
+  RCam cam;
+  unsigned char colors[16][3];
+  const int* seg_g;  // [N][seg_cap][5]
+  const int* seg_n;  // [N]
+  int seg_cap;
+  unsigned char* obs;
+  const unsigned char* mask;  // reset mask (NULL = all envs)
+  int off_tab, off_bits;
+  unsigned int flags;
+};
+
+#ifndef TC_RASTER_WAVES
+#define TC_RASTER_WAVES 4
+#endif
+template <bool THICK, int FMT>
+__global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int env = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (env >= a.N) return;
+  if (a.mask && !a.mask[env]) return;
+  const RCam& cam = a.cam;
+  unsigned int* bits = (unsigned int*)(smem + a.off_bits);
+  const int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;
+  const int nseg = a.seg_n[env];
+
+  const int H = cam.H, W = cam.W, wpr = cam.wpr, C = a.C;
+  unsigned char* out = a.obs + (size_t)env * ((size_t)H * W * (FMT == TC_FMT_CLASSES ? C : 3));
+  int* lt = (int*)(smem + a.off_tab);     // [RB*4][5] outline-edge parameters
+  int* lc = lt + RB * 4 * 5;              // [RB*4] chunks per outline edge, then exclusive prefix
+  int* fl = lc + RB * 4;                  // [RB] first fill row
+  int* fh = fl + RB;                      // [RB] last fill row
+  int* fc = fh + RB;                      // [RB] fill chunks, then exclusive prefix
+  int* fd = fc + RB;                      // [RB][2] ThickLine's (dp.x, dp.y) of the segment
   for (int band = 0; band < cam.n_bands; band++) {
     const int y0 = band * cam.band_rows;
     const int y1 = (y0 + cam.band_rows < H) ? y0 + cam.band_rows : H;
@@ -354,36 +433,151 @@ __global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const 
     const int nwords = C * cam.band_rows * wpr;
     for (int i = tid; i < nwords; i += TC_NT) bits[i] = 0;
     __syncthreads();
-    for (int k = tid; k < nseg && !(flags & DBG_SKIP_RASTER); k += TC_NT) {
-      const int* sg = seg + 5 * k;
-      Ras r;
-      r.bits = bits + sg[0] * cam.band_rows * wpr;
-      r.W = W;
-      r.H = H;
-      r.wpr = wpr;
-      r.y0 = y0;
-      r.y1 = y1;
-      r_thick_line(r, sg[1], sg[2], sg[3], sg[4], cam.thickness);
+    Ras r;
+    r.W = W;
+    r.H = H;
+    r.wpr = wpr;
+    r.y0 = y0;
+    r.y1 = y1;
+    const int plane = cam.band_rows * wpr;
+    if (a.flags & DBG_SKIP_RASTER) {
+    } else if (!THICK) {
+      for (int k = tid; k < nseg; k += TC_NT) {
+        const int* sg = segg + 5 * k;
+        r.bits = bits + sg[0] * plane;
+        r_line_bresenham(r, sg[1], sg[2], sg[3], sg[4]);  // ThickLine with thickness <= 1 is a plain Line()
+      }
+    } else {
+      // ThickLine = FillConvexPoly(quad) [4 Line2 outline edges + scanline fill] + 2 round caps.
+      // Segments are taken RB at a time; their pixel work is cut into small uniform chunks that are
+      // dealt to the 64 lanes through prefix sums, so one long line does not serialise the wave.
+      for (int base = 0; base < nseg; base += RB) {
+        const int nb = nseg - base < RB ? nseg - base : RB;
+        for (int t = tid; t < RB * 4; t += TC_NT) {  // outline edges: clip + DDA parameters
+          int nchunk = 0;
+          if (t < nb * 4) {
+            const int k = base + (t >> 2), e = t & 3;
+            const int* sg = segg + 5 * k;
+            long long qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3;
+            if (r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
+              // FillConvexPoly walks p0 = v[3]; Line2(p0, v[i]); p0 = v[i]
+              long long ax = sel4(qx3, qx0, qx1, qx2, e), ay = sel4(qy3, qy0, qy1, qy2, e);
+              long long bx = sel4(qx0, qx1, qx2, qx3, e), by = sel4(qy0, qy1, qy2, qy3, e);
+              LineP L = r_line2_setup(W, H, ax, ay, bx, by);
+              if (L.ecount >= 0) {
+                r.bits = bits + sg[0] * plane;
+                r_put(r, L.ex, L.ey);
+                int* o = lt + 5 * t;
+                o[0] = L.a;
+                o[1] = L.b;
+                o[2] = L.step;
+                o[3] = L.ecount | (L.xmajor << 30);
+                o[4] = sg[0];
+                nchunk = (L.ecount + LCH) / LCH;
+              }
+            }
+          }
+          lc[t] = nchunk;
+        }
+        if (tid < RB) {  // fill rows of this band
+          int nchunk = 0, lo = 0, hi = -1;
+          if (tid < nb) {
+            const int k = base + tid;
+            const int* sg = segg + 5 * k;
+            long long qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3;
+            if (r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
+              r_fill_row_range(W, H, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, lo, hi);
+              if (lo < y0) lo = y0;
+              if (hi > y1 - 1) hi = y1 - 1;
+              if (hi >= lo) nchunk = (hi - lo + FCH) / FCH;
+              fd[2 * tid] = (int)(qx0 - (long long)sg[1] * TC_XY_ONE);      // dp.x
+              fd[2 * tid + 1] = (int)(qy0 - (long long)sg[2] * TC_XY_ONE);  // dp.y
+            }
+          }
+          fl[tid] = lo;
+          fh[tid] = hi;
+          fc[tid] = nchunk;
+        }
+        __syncthreads();
+        int tot_l, tot_f;
+        {  // exclusive prefix sums (RB*4 = 2 entries per lane; RB entries on the low lanes)
+          int v0 = lc[2 * tid], v1 = lc[2 * tid + 1];
+          int inc = wave_incl_scan(v0 + v1);
+          tot_l = __shfl(inc, TC_NT - 1);
+          int f = tid < RB ? fc[tid] : 0;
+          int finc = wave_incl_scan(f);
+          tot_f = __shfl(finc, TC_NT - 1);
+          lc[2 * tid] = inc - v0 - v1;  // each lane rewrites only the entries it read
+          lc[2 * tid + 1] = inc - v1;
+          if (tid < RB) fc[tid] = finc - f;
+        }
+        __syncthreads();
+        for (int c = tid; c < tot_l && !(a.flags & DBG_SKIP_R2); c += TC_NT) {  // outline pixels, LCH steps per chunk
+          int lo = 0, hi = RB * 4;
+          while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (lc[mid] <= c) lo = mid; else hi = mid;
+          }
+          const int* o = lt + 5 * lo;
+          const int ecount = o[3] & 0xffff, xmajor = (o[3] >> 30) & 1;
+          const int k0 = (c - lc[lo]) * LCH;
+          const int k1 = k0 + LCH - 1 < ecount ? k0 + LCH - 1 : ecount;
+          r.bits = bits + o[4] * plane;
+          r_line2_pixels(r, o[0], o[1], o[2], xmajor, k0, k1);
+        }
+        for (int c = tid; c < tot_f && !(a.flags & DBG_SKIP_R3); c += TC_NT) {  // scanline fill, FCH rows per chunk
+          int lo = 0, hi = RB;
+          while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (fc[mid] <= c) lo = mid; else hi = mid;
+          }
+          const int k = base + lo;
+          const int* sg = segg + 5 * k;
+          const long long p0x = (long long)sg[1] * TC_XY_ONE, p0y = (long long)sg[2] * TC_XY_ONE;
+          const long long p1x = (long long)sg[3] * TC_XY_ONE, p1y = (long long)sg[4] * TC_XY_ONE;
+          const long long dpx = fd[2 * lo], dpy = fd[2 * lo + 1];
+          const long long qx0 = p0x + dpx, qx1 = p0x - dpx, qx2 = p1x - dpx, qx3 = p1x + dpx;
+          const long long qy0 = p0y + dpy, qy1 = p0y - dpy, qy2 = p1y - dpy, qy3 = p1y + dpy;
+          const int row_lo = fl[lo] + (c - fc[lo]) * FCH;
+          const int row_hi = row_lo + FCH < fh[lo] + 1 ? row_lo + FCH : fh[lo] + 1;
+          r.bits = bits + sg[0] * plane;
+          r_fill_rows(r, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, row_lo, row_hi);
+        }
+        for (int t = tid; t < nb * 2 && !(a.flags & DBG_SKIP_R4); t += TC_NT) {  // round caps (flags = 3: both ends)
+          const int k = base + (t >> 1);
+          const int* sg = segg + 5 * k;
+          r.bits = bits + sg[0] * plane;
+          const int cx = (t & 1) ? sg[3] : sg[1], cy = (t & 1) ? sg[4] : sg[2];
+          if (cam.cap_r < 32)
+            r_cap(r, cx, cy, cam.cap_r, cam.cap_hw);
+          else
+            r_circle_fill(r, cx, cy, cam.cap_r);
+        }
+        __syncthreads();
+      }
     }
     __syncthreads();
-    if (flags & DBG_SKIP_STORE) {
-    } else if (cam.format == TC_FMT_CLASSES) {
+    if (a.flags & DBG_SKIP_STORE) {
+    } else if (FMT == TC_FMT_CLASSES) {
       if ((W & 15) == 0) {
         // 16 pixels -> one 16-byte store per lane, consecutive lanes on consecutive addresses
-        const int per_plane = rows * W / 16;
-        const int total = C * per_plane;
-        for (int q = tid; q < total; q += TC_NT) {
-          int c = q / per_plane, r16 = q - c * per_plane;
-          int pix = r16 * 16;
-          int yy = pix / W, xx = pix - yy * W;
-          unsigned int word = bits[(c * cam.band_rows + yy) * wpr + (xx >> 5)];
-          unsigned int b16 = (word >> (xx & 31)) & 0xffffu;
-          uint4 o;
-          o.x = spread4(b16);
-          o.y = spread4(b16 >> 4);
-          o.z = spread4(b16 >> 8);
-          o.w = spread4(b16 >> 12);
-          *(uint4*)(out + ((size_t)c * H + y0 + yy) * W + xx) = o;
+        const int g = W >> 4;                            // 16-pixel groups per row
+        const int gs = (g & (g - 1)) == 0 ? __ffs(g) - 1 : -1;
+        const int per_plane = rows * g;
+        for (int c = 0; c < C; c++) {
+          const unsigned int* pl = bits + c * cam.band_rows * wpr;
+          unsigned char* po = out + ((size_t)c * H + y0) * W;
+          for (int q = tid; q < per_plane; q += TC_NT) {
+            const int yy = gs >= 0 ? q >> gs : q / g;
+            const int xx = (q - yy * g) << 4;
+            const unsigned int b16 = (pl[yy * wpr + (xx >> 5)] >> (xx & 31)) & 0xffffu;
+            uint4 o;
+            o.x = spread4(b16 & 15u);
+            o.y = spread4((b16 >> 4) & 15u);
+            o.z = spread4((b16 >> 8) & 15u);
+            o.w = spread4(b16 >> 12);
+            *(uint4*)(po + (size_t)q * 16) = o;  // rows of a plane are contiguous: group q sits at byte 16 q
+          }
         }
       } else {
         const int per_plane = rows * W;
@@ -402,17 +596,19 @@ __global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const 
         for (int g = tid; g < total; g += TC_NT) {
           int pix = g * 4;
           int yy = pix / W, xx = pix - yy * W;
+          unsigned int top4 = 0;  // per pixel: 1 + index of the highest layer set, 4 pixels in 4 bytes
+          for (int c = 0; c < C; c++) {
+            unsigned int word = bits[(c * cam.band_rows + yy) * wpr + (xx >> 5)];
+            unsigned int m4 = spread4((word >> (xx & 31)) & 15u);  // 0xFF where the layer covers the pixel
+            top4 = (top4 & ~m4) | (m4 & (0x01010101u * (unsigned)(c + 1)));
+          }
           unsigned char px[12];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            int top = -1;
-            for (int c = 0; c < C; c++) {
-              unsigned int word = bits[(c * cam.band_rows + yy) * wpr + ((xx + k) >> 5)];
-              if ((word >> ((xx + k) & 31)) & 1u) top = c;
-            }
-            px[3 * k] = top >= 0 ? m.colors[top][0] : 0;
-            px[3 * k + 1] = top >= 0 ? m.colors[top][1] : 0;
-            px[3 * k + 2] = top >= 0 ? m.colors[top][2] : 0;
+            int top = (int)((top4 >> (8 * k)) & 255u) - 1;
+            px[3 * k] = top >= 0 ? a.colors[top][0] : 0;
+            px[3 * k + 1] = top >= 0 ? a.colors[top][1] : 0;
+            px[3 * k + 2] = top >= 0 ? a.colors[top][2] : 0;
           }
           unsigned int* o = (unsigned int*)(out + ((size_t)(y0 + yy) * W + xx) * 3);
           o[0] = px[0] | (px[1] << 8) | (px[2] << 16) | ((unsigned)px[3] << 24);
@@ -429,9 +625,9 @@ __global__ __launch_bounds__(TC_NT) void tc_env_kernel(KArgs a, int mode, const 
             if ((word >> (xx & 31)) & 1u) top = c;
           }
           unsigned char* o = out + ((size_t)(y0 + yy) * W + xx) * 3;
-          o[0] = top >= 0 ? m.colors[top][0] : 0;
-          o[1] = top >= 0 ? m.colors[top][1] : 0;
-          o[2] = top >= 0 ? m.colors[top][2] : 0;
+          o[0] = top >= 0 ? a.colors[top][0] : 0;
+          o[1] = top >= 0 ? a.colors[top][1] : 0;
+          o[2] = top >= 0 ? a.colors[top][2] : 0;
         }
       }
     }
@@ -467,6 +663,7 @@ struct tc_env {
   KArgs k;
   bool bound;
   int64_t obs_bytes;
+  int r_off_tab, r_off_bits, r_lds;
 };
 
 template <typename T>
@@ -535,13 +732,16 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
       }
     }
   std::vector<double2> nodes(TN), lpn(lpN);
-  std::vector<int2> edges(TE), lpe(lpE);
+  std::vector<int2> edges(TE), lpe(lpE), edges_g(TE);
+  std::vector<int> edge_layer(TE);
   std::vector<double> of(TE), orv(TE), lpo(lpE), nori(lpE), pori(lpE);
   std::vector<int> noff(lpN + 1, 0), poff(lpN + 1, 0), nnode(lpE), pnode(lpE);
   for (int i = 0; i < TN; i++) nodes[i] = make_double2(desc->nodes[2 * i], desc->nodes[2 * i + 1]);
   for (int l = 0; l < C; l++)
     for (int e = d.edge_off[l]; e < d.edge_off[l + 1]; e++) {
       edges[e] = make_int2(desc->edges[2 * e], desc->edges[2 * e + 1]);
+      edges_g[e] = make_int2(d.node_off[l] + edges[e].x, d.node_off[l] + edges[e].y);
+      edge_layer[e] = l;
       double2 a = nodes[d.node_off[l] + edges[e].x], b = nodes[d.node_off[l] + edges[e].y];
       double evx = b.x - a.x, evy = b.y - a.y;
       // static halves of layer.py:140-141, evaluated with the host libm like the reference does
@@ -586,7 +786,7 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
   HIP_TRY(hipGetDevice(&m->device));
 #define UP(vec, field)                                             \
   if (rc == TC_OK) rc = upload(m, vec, &d.field);
-  UP(nodes, nodes) UP(edges, edges) UP(of, ori_fwd) UP(orv, ori_rev) UP(lpn, lp_nodes) UP(lpe, lp_edges)
+  UP(nodes, nodes) UP(edges, edges) UP(edges_g, edges_g) UP(edge_layer, edge_layer) UP(of, ori_fwd) UP(orv, ori_rev) UP(lpn, lp_nodes) UP(lpe, lp_edges)
   UP(lpo, lp_ori) UP(noff, next_off) UP(nnode, next_node) UP(nori, next_ori) UP(poff, prev_off)
   UP(pnode, prev_node) UP(pori, prev_ori)
 #undef UP
@@ -601,7 +801,8 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
 static int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 static int fill_camera(tc_env* e, const tc_camera_params* cam) {
-  if (cam->height < 1 || cam->width < 1 || cam->line_thickness < 1 || !(cam->max_range > 0) ||
+  if (cam->height < 1 || cam->width < 1 || cam->height > 16384 || cam->width > 16384 || cam->line_thickness < 1 ||
+      cam->line_thickness > 255 || !(cam->max_range > 0) ||
       (cam->format != TC_FMT_RGB && cam->format != TC_FMT_CLASSES)) {
     set_err("camera: need height,width,line_thickness >= 1, max_range > 0, format rgb|classes");
     return TC_E_INVALID;
@@ -660,25 +861,30 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   dc.n_bands = (dc.H + band_rows - 1) / band_rows;
   LdsLayout& L = e->k.lds;
   int off = 0;
-  L.off_p = off;
-  int pcount = 3 * m.max_nodes > m.total_nodes ? 3 * m.max_nodes : m.total_nodes;
-  off += align_up(pcount * 8, 16);
+  L.off_p = off;  // node buffer: 3 doubles per lane-line node (all layers)
+  int pbytes = 3 * m.total_nodes * 8;
+  off += align_up(pbytes, 16);
   L.off_flg = off;
-  off += align_up(m.max_nodes, 16);
-  L.off_list = off;
-  off += align_up(m.max_edges * 4, 16);
-  L.off_seg = off;
-  L.seg_cap = m.total_edges;
-  off += align_up(L.seg_cap * 5 * 4, 16);
-  L.off_bits = off;
-  off += align_up(m.C * band_rows * dc.wpr * 4, 16);
+  off += align_up(m.total_nodes, 16);
+  L.off_list = off;  // fix-up edge list / projection candidate list
+  off += align_up((m.total_edges > m.total_nodes ? m.total_edges : m.total_nodes) * 4, 16);
   L.off_cnt = off;
-  off += 16;
+  off += 64;
   L.total = off;
-  if (L.total > 160 * 1024) {
+  // raster kernel: tables + bit-planes of one band
+  e->r_off_tab = 0;
+  e->r_off_bits = align_up((RB * 4 * 5 + RB * 4 + 5 * RB) * 4, 16);
+  e->r_lds = e->r_off_bits + align_up(m.C * band_rows * dc.wpr * 4, 16);
+  if (L.total > 160 * 1024 || e->r_lds > 160 * 1024) {
     set_err("tc_env_create: map too large for one workgroup's LDS");
     delete e;
     return TC_E_LDS;
+  }
+  if (e->r_lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)tc_raster_kernel<true, TC_FMT_CLASSES>, hipFuncAttributeMaxDynamicSharedMemorySize, e->r_lds);
+    (void)hipFuncSetAttribute((const void*)tc_raster_kernel<true, TC_FMT_RGB>, hipFuncAttributeMaxDynamicSharedMemorySize, e->r_lds);
+    (void)hipFuncSetAttribute((const void*)tc_raster_kernel<false, TC_FMT_CLASSES>, hipFuncAttributeMaxDynamicSharedMemorySize, e->r_lds);
+    (void)hipFuncSetAttribute((const void*)tc_raster_kernel<false, TC_FMT_RGB>, hipFuncAttributeMaxDynamicSharedMemorySize, e->r_lds);
   }
   if (L.total > 48 * 1024) {
     hipError_t he = hipFuncSetAttribute((const void*)tc_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
@@ -689,17 +895,34 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
     }
   }
   e->obs_bytes = (int64_t)dc.H * dc.W * (dc.format == TC_FMT_CLASSES ? m.C : 3);
+  e->k.seg_cap = m.total_edges > 0 ? m.total_edges : 1;
+  {
+    void *p = nullptr, *q = nullptr;
+    hipError_t he = hipMalloc(&p, (size_t)num_envs * e->k.seg_cap * 5 * sizeof(int));
+    if (he == hipSuccess) he = hipMalloc(&q, (size_t)num_envs * sizeof(int));
+    if (he == hipSuccess) he = hipMemset(q, 0, (size_t)num_envs * sizeof(int));
+    if (he != hipSuccess) {
+      set_err(std::string("hipMalloc(draw list): ") + hipGetErrorString(he));
+      if (p) (void)hipFree(p);
+      delete e;
+      return TC_E_NOMEM;
+    }
+    e->k.seg_g = (int*)p;
+    e->k.seg_n = (int*)q;
+  }
   *out = e;
   return TC_OK;
 }
 
 extern "C" int tc_env_destroy(tc_env* e) {
+  if (e && e->k.seg_g) (void)hipFree(e->k.seg_g);
+  if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
   delete e;
   return TC_OK;
 }
 
 extern "C" int64_t tc_env_obs_bytes(const tc_env* e) { return e ? e->obs_bytes : TC_E_INVALID; }
-extern "C" int64_t tc_env_lds_bytes(const tc_env* e) { return e ? e->k.lds.total : TC_E_INVALID; }
+extern "C" int64_t tc_env_lds_bytes(const tc_env* e) { return e ? (e->k.lds.total > e->r_lds ? e->k.lds.total : e->r_lds) : TC_E_INVALID; }
 
 extern "C" int tc_env_bind(tc_env* e, const tc_buffers* b) {
   if (!e || !b) return TC_E_INVALID;
@@ -745,6 +968,47 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   hipLaunchKernelGGL(tc_env_kernel, dim3(e->k.N), dim3(TC_NT), e->k.lds.total, (hipStream_t)stream, e->k, mode, cc,
                      cdtype, man, spawn, mask, flags);
   HIP_TRY(hipGetLastError());
+  if (!(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs) {
+    RArgs r;
+    memset(&r, 0, sizeof(r));
+    r.N = e->k.N;
+    r.C = e->k.m.C;
+    const DevCam& c = e->k.cam;
+    r.cam.H = c.H; r.cam.W = c.W; r.cam.wpr = c.wpr; r.cam.band_rows = c.band_rows; r.cam.n_bands = c.n_bands;
+    r.cam.thickness = c.thickness; r.cam.format = c.format;
+    {  // Circle(center, radius, fill) of drawing.cpp run once on the host: per-row half widths
+      int radius = (int)((((long long)c.thickness << 15) + 32768) >> 16);
+      r.cam.cap_r = radius;
+      if (radius < 32) {
+        int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+        while (dx >= dy) {
+          if (r.cam.cap_hw[dy] < dx) r.cam.cap_hw[dy] = (unsigned char)dx;
+          if (r.cam.cap_hw[dx] < dy) r.cam.cap_hw[dx] = (unsigned char)dy;
+          dy++;
+          err += plus;
+          plus += 2;
+          int mask = (err <= 0) - 1;
+          err -= minus & mask;
+          dx += mask;
+          minus -= mask & 2;
+        }
+      }
+    }
+    memcpy(r.colors, e->k.m.colors, sizeof(r.colors));
+    r.seg_g = e->k.seg_g;
+    r.seg_n = e->k.seg_n;
+    r.seg_cap = e->k.seg_cap;
+    r.obs = e->k.b.obs;
+    r.mask = mode == MODE_RESET ? mask : nullptr;
+    r.off_tab = e->r_off_tab;
+    r.off_bits = e->r_off_bits;
+    r.flags = flags;
+    const bool thick = c.thickness > 1, cls = c.format == TC_FMT_CLASSES;
+    auto kern = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
+                      : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
+    hipLaunchKernelGGL(kern, dim3(e->k.N), dim3(TC_NT), e->r_lds, (hipStream_t)stream, r);
+    HIP_TRY(hipGetLastError());
+  }
   return TC_OK;
 }
 
