@@ -20,6 +20,18 @@
 #define TC_NT 64  // threads per workgroup == wavefront size
 #define TC_PI 3.141592653589793
 
+// Lanepath node with its adjacency inlined, so that lanepath tracking (car.py:127-148) costs one memory
+// round trip per visited node instead of one per CSR array touched.  Lists longer than 3 keep their
+// true length in nnext / nprev and are then read from the CSR arrays instead.
+struct LpNode {
+  double x, y;
+  int nnext, nprev;
+  int next[3];
+  int prev[3];
+  double next_ori[3];  // atan2(nodes[next[k]] - this)  (layer.py:122 / 179-181)
+  double prev_ori[3];  // atan2(nodes[prev[k]] - this)
+};
+
 struct DevMap {
   int C;
   int node_off[17];
@@ -34,6 +46,7 @@ struct DevMap {
   unsigned char colors[16][3];
   int lpN, lpE;
   int first_spawnable;    // a lanepath node with an out-edge (fallback for invalid spawn requests)
+  const struct LpNode* lp_fat;  // one record per lanepath node: position + first 3 next/prev neighbours
   const double2* lp_nodes;
   const int2* lp_edges;
   const double* lp_ori;   // per lanepath edge orientation
@@ -160,6 +173,64 @@ __device__ inline int d_pick_node(const int* lst, const double* ori, int s0, int
   return lst[s0 + best];
 }
 
+// ---- the same two queries on an inlined LpNode record (fallback to CSR when a list has > 3 entries)
+__device__ inline int sel3i(int a0, int a1, int a2, int i) {
+  int r = a0;
+  r = i == 1 ? a1 : r;
+  r = i == 2 ? a2 : r;
+  return r;
+}
+
+__device__ inline double d_edge_ori_f(const DevMap& m, const LpNode& A, int a, int b) {
+  if (A.nnext <= 3) {
+    if (A.nnext > 0 && A.next[0] == b) return A.next_ori[0];
+    if (A.nnext > 1 && A.next[1] == b) return A.next_ori[1];
+    if (A.nnext > 2 && A.next[2] == b) return A.next_ori[2];
+  }
+  return d_lp_edge_ori(m, a, b);
+}
+
+// layer.py:105-124 on up to 3 inlined neighbours
+__device__ inline int d_pick3(int l0, int l1, int l2, double o0, double o1, double o2, int n, int node_idx,
+                              double orientation, int& status) {
+  if (n == 0) return -1;
+  if (n <= 1) return l0;
+  int best = -1, k = 0;
+  double bk = 0;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int lj = j == 0 ? l0 : j == 1 ? l1 : l2;
+    const double oj = j == 0 ? o0 : j == 1 ? o1 : o2;
+    if (j < n && lj != node_idx) {
+      double key = tc_fabs(d_clip_angle(oj - orientation));
+      if (best < 0 || key < bk) {
+        best = k;
+        bk = key;
+      }
+      k++;
+    }
+  }
+  if (best < 0) {
+    status |= 2;  // TC_S_PICK_EMPTY
+    return -1;
+  }
+  return sel3i(l0, l1, l2, best);  // index into the UNFILTERED list (layer.py:122-124)
+}
+
+__device__ inline int d_pick_next_f(const DevMap& m, const LpNode& A, int node_idx, double orientation, int& status) {
+  if (A.nnext <= 3)
+    return d_pick3(A.next[0], A.next[1], A.next[2], A.next_ori[0], A.next_ori[1], A.next_ori[2], A.nnext, node_idx,
+                   orientation, status);
+  return d_pick_node(m.next_node, m.next_ori, m.next_off[node_idx], m.next_off[node_idx + 1], node_idx, orientation, status);
+}
+
+__device__ inline int d_pick_prev_f(const DevMap& m, const LpNode& A, int node_idx, double orientation, int& status) {
+  if (A.nprev <= 3)
+    return d_pick3(A.prev[0], A.prev[1], A.prev[2], A.prev_ori[0], A.prev_ori[1], A.prev_ori[2], A.nprev, node_idx,
+                   orientation, status);
+  return d_pick_node(m.prev_node, m.prev_ori, m.prev_off[node_idx], m.prev_off[node_idx + 1], node_idx, orientation, status);
+}
+
 // layer.py:59-74 over the lanepath, all 64 lanes cooperating; returns edge index or -1
 __device__ inline int d_nearest_edge_with_orientation(const DevMap& m, double px, double py, double orientation,
                                                       double margin_deg) {
@@ -189,15 +260,14 @@ __device__ inline void d_update_front(const DevCar& c, CarState& s) {  // car.py
 
 // car.py:34-44 + map.py:62-69 with the spawn node already drawn
 __device__ inline void d_reset(const DevMap& m, const DevCar& c, CarState& s, int node) {
-  int s0 = m.next_off[node];
-  double2 p = m.lp_nodes[node];
-  s.x = p.x;
-  s.y = p.y;
-  s.theta = m.next_ori[s0];
+  const LpNode F = m.lp_fat[node];
+  s.x = F.x;
+  s.y = F.y;
+  s.theta = F.next_ori[0];
 #pragma unroll
   for (int i = 0; i < 8; i++) s.lp[i] = -1;
   s.lp[0] = node;
-  s.lp[1] = m.next_node[s0];
+  s.lp[1] = F.next[0];
   s.lp_len = 1;
   d_update_front(c, s);
   s.steering = 0.0;
@@ -206,11 +276,19 @@ __device__ inline void d_reset(const DevMap& m, const DevCar& c, CarState& s, in
   s.last_maneuver = 0;
 }
 
+// What car.get_info needs about local_path[1] (car.py:52-53), captured while the records are in registers
+struct PathInfo {
+  double ax, ay, bx, by;  // nodes of local_path[1]
+  double ori;             // orientation of local_path[1]
+  int valid;              // 0: local_path was left untouched (early truncation) -> read it from the tables
+};
+
 // car.py:127-148
-__device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuver, int& status) {
+__device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuver, int& status, PathInfo& pi) {
   double fx = s.front_x, fy = s.front_y;
   int e0 = s.lp[0], e1 = s.lp[1];
-  double mdir = d_clip_angle(d_lp_edge_ori(m, e0, e1) + (maneuver * TC_PI) / 2);
+  const LpNode N0 = m.lp_fat[e0], N1 = m.lp_fat[e1];
+  double mdir = d_clip_angle(d_edge_ori_f(m, N0, e0, e1) + (maneuver * TC_PI) / 2);
   int ne0, ne1;
   if (maneuver == 2 && s.last_maneuver != 2) {  // wave-uniform branch
     int e = d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0);
@@ -223,11 +301,11 @@ __device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuv
     ne0 = ed.x;
     ne1 = ed.y;
   } else {  // layer.py:77-103
-    int nx = d_pick_node(m.next_node, m.next_ori, m.next_off[e1], m.next_off[e1 + 1], e1, mdir, status);
-    int pv = d_pick_node(m.prev_node, m.prev_ori, m.prev_off[e0], m.prev_off[e0 + 1], e0, mdir, status);
+    int nx = d_pick_next_f(m, N1, e1, mdir, status);
+    int pv = d_pick_prev_f(m, N0, e0, mdir, status);
     if (nx < 0 || pv < 0) return 1;
-    double2 n0 = m.lp_nodes[e0], n1 = m.lp_nodes[e1], nn = m.lp_nodes[nx], np = m.lp_nodes[pv];
-    double d0 = d_dist(fx, fy, n0.x, n0.y), d1 = d_dist(fx, fy, n1.x, n1.y);
+    double2 nn = m.lp_nodes[nx], np = m.lp_nodes[pv];
+    double d0 = d_dist(fx, fy, N0.x, N0.y), d1 = d_dist(fx, fy, N1.x, N1.y);
     double dn = d_dist(fx, fy, nn.x, nn.y), dp = d_dist(fx, fy, np.x, np.y);
     if (dn < d0 && dn < d1) {
       ne0 = e1;
@@ -244,24 +322,42 @@ __device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuv
   s.lp[0] = ne0;
   s.lp[1] = ne1;
   s.lp_len = 1;
-  int last0 = ne0, last1 = ne1;
+  const bool fwd = s.velocity > 0;  // car.py:143
+  int node = fwd ? ne1 : ne0;
+  LpNode A = m.lp_fat[node];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    int node = s.velocity > 0 ? last1 : last0;  // car.py:143
-    int nn = d_pick_node(m.next_node, m.next_ori, m.next_off[node], m.next_off[node + 1], node, mdir, status);
+    int nn = d_pick_next_f(m, A, node, mdir, status);
     if (nn < 0) return 1;
     s.lp[2 * (i + 1)] = node;
     s.lp[2 * (i + 1) + 1] = nn;
     s.lp_len = i + 2;
-    last0 = node;
-    last1 = nn;
+    if (i == 0) {
+      pi.valid = 1;
+      pi.ax = A.x;
+      pi.ay = A.y;
+      pi.ori = d_edge_ori_f(m, A, node, nn);
+      if (!fwd) {  // the next record loaded is `node` again: fetch nn's position on its own
+        double2 q = m.lp_nodes[nn];
+        pi.bx = q.x;
+        pi.by = q.y;
+      }
+    }
+    if (fwd) {  // velocity > 0: continue from the new end node; otherwise from the same start node
+      node = nn;
+      if (i < 2) A = m.lp_fat[node];
+      if (i == 0) {
+        pi.bx = A.x;
+        pi.by = A.y;
+      }
+    }
   }
   return 0;
 }
 
 // car.py:70-125; returns truncated
 __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, double v_in, double s_in, int maneuver,
-                                 int& status) {
+                                 int& status, PathInfo& pi) {
   double dt = c.T;
   double nv = v_in * c.max_velocity;
   if (c.has_max_acceleration)
@@ -293,7 +389,7 @@ __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, 
       s.theta += 2 * TC_PI;
   }
   d_update_front(c, s);
-  return d_find_local_path(m, s, maneuver, status);
+  return d_find_local_path(m, s, maneuver, status, pi);
 }
 
 // ------------------------------------------------------------------ camera.py helpers
@@ -681,6 +777,125 @@ __device__ inline void r_fill_rows(const Ras& r, long long qx0, long long qx1, l
       y += (int)(k - 1);
     }
   } while (++y <= last);
+}
+
+// FillConvexPoly's two edge walkers as closed-form pieces.  The scanline loop of drawing.cpp is a
+// sequence of "events" (a walker reaches the end row of its polygon edge and picks the next one, with a
+// shared budget of npts edges) between which both walkers just add dx per row.  This runs the event
+// part literally -- only at event rows -- and records every new piece (start row, x at that row, dx per
+// row, walker id); row r of walker w is then xs + (r - y_start) * dx of its latest piece.  At most 4
+// pieces (every successful update consumes at least one of the 4 edges).
+//   py/px/pdx: LDS tables [4]; returns number of pieces; wmask bit s = walker of piece s;
+//   rows [y_first, y_last] are the ones the fill draws (empty when y_last < y_first).
+__device__ inline int r_fill_events(int W, int H, long long qx0, long long qx1, long long qx2, long long qx3,
+                                    long long qy0, long long qy1, long long qy2, long long qy3, int* py, int* pv,
+                                    int& wmask, int& y_first, int& y_last) {
+  // Integer-only part: which polygon edge each walker switches to at which row.  pv[s] = idx0 | idx << 2
+  // (xs = vx[idx0], xe = vx[idx], end row = ty[idx]); the slope of piece s is computed by r_fill_slope.
+  const int npts = 4, shift = TC_XY_SHIFT;
+  const int delta = 1 << shift >> 1;
+  wmask = 0;
+  y_first = 0;
+  y_last = -1;
+  int imin = 0;
+  long long xmin = qx0, xmax = qx0, ymin = qy0, ymax = qy0;
+#pragma unroll
+  for (int i = 1; i < npts; i++) {
+    long long x = sel4(qx0, qx1, qx2, qx3, i), y = sel4(qy0, qy1, qy2, qy3, i);
+    if (y < ymin) {
+      ymin = y;
+      imin = i;
+    }
+    if (y > ymax) ymax = y;
+    if (x > xmax) xmax = x;
+    if (x < xmin) xmin = x;
+  }
+  xmin = (xmin + delta) >> shift;
+  xmax = (xmax + delta) >> shift;
+  ymin = (ymin + delta) >> shift;
+  ymax = (ymax + delta) >> shift;
+  if (d_wrap32(xmax) < 0 || d_wrap32(ymax) < 0 || d_wrap32(xmin) >= W || d_wrap32(ymin) >= H) return 0;
+  if (ymax > H - 1) ymax = H - 1;
+  const int ty0 = d_wrap32((qy0 + delta) >> shift), ty1 = d_wrap32((qy1 + delta) >> shift);
+  const int ty2 = d_wrap32((qy2 + delta) >> shift), ty3 = d_wrap32((qy3 + delta) >> shift);
+  int y = d_wrap32(ymin);
+  int e_idx0 = imin, e_idx1 = imin, e_ye0 = y, e_ye1 = y;
+  int edges = npts, np = 0;
+  int y_end = (int)ymax + 1;
+  for (int guard = 0; guard < 8; guard++) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int ye = i ? e_ye1 : e_ye0;
+      if (y >= ye) {
+        int idx0 = i ? e_idx1 : e_idx0;
+        const int di = i ? npts - 1 : 1;
+        int idx = idx0 + di;
+        if (idx >= npts) idx -= npts;
+        for (; edges-- > 0;) {
+          int ty = idx == 0 ? ty0 : idx == 1 ? ty1 : idx == 2 ? ty2 : ty3;
+          if (ty > y) {
+            py[np] = y;
+            pv[np] = idx0 | (idx << 2);
+            wmask |= i << np;
+            np++;
+            if (i) {
+              e_ye1 = ty;
+              e_idx1 = idx;
+            } else {
+              e_ye0 = ty;
+              e_idx0 = idx;
+            }
+            break;
+          }
+          idx0 = idx;
+          idx += di;
+          if (idx >= npts) idx -= npts;
+        }
+      }
+    }
+    if (edges < 0) {
+      y_end = y;
+      break;
+    }
+    int ynext = e_ye0 < e_ye1 ? e_ye0 : e_ye1;
+    if (ynext > (int)ymax) break;
+    y = ynext;
+  }
+  y_first = d_wrap32(ymin) > 0 ? d_wrap32(ymin) : 0;
+  y_last = y_end - 1 < (int)ymax ? y_end - 1 : (int)ymax;
+  return np;
+}
+
+// slope of one recorded piece (drawing.cpp: edge[i].dx = ((xe - xs)*2 + (ty - y)) / (2*(ty - y)), edge[i].x = xs)
+__device__ inline void r_fill_slope(long long qx0, long long qx1, long long qx2, long long qx3, long long qy0,
+                                    long long qy1, long long qy2, long long qy3, int y_u, int v, long long& xs,
+                                    long long& dx) {
+  const int idx0 = v & 3, idx = (v >> 2) & 3;
+  const int ty = d_wrap32((sel4(qy0, qy1, qy2, qy3, idx) + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
+  xs = sel4(qx0, qx1, qx2, qx3, idx0);
+  const long long xe = sel4(qx0, qx1, qx2, qx3, idx);
+  dx = d_sdiv((xe - xs) * 2 + ((long long)ty - y_u), 2 * ((long long)ty - y_u));
+}
+
+// one fill row from the piece table
+__device__ inline void r_fill_row(const Ras& r, int row, int np, int wmask, const int* py, const long long* px,
+                                  const long long* pdx) {
+  long long xa = -TC_XY_ONE, xb = -TC_XY_ONE;
+  for (int s = 0; s < np; s++) {
+    const int ys = py[s];
+    if (ys <= row) {
+      long long x = px[s] + (long long)(row - ys) * pdx[s];
+      if ((wmask >> s) & 1)
+        xb = x;
+      else
+        xa = x;
+    }
+  }
+  long long xl = xa < xb ? xa : xb, xr = xa < xb ? xb : xa;
+  int xx1 = d_wrap32((xl + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
+  int xx2 = d_wrap32((xr + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
+  const bool ok = xx2 >= 0 && xx1 < r.W;
+  r_hline(r, ok ? row : -1, xx1, xx2);
 }
 
 // rows of the image a FillConvexPoly of this quad can touch: [lo, hi], empty when lo > hi

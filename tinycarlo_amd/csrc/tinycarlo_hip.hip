@@ -120,13 +120,14 @@ __device__ inline void cam_fixup_pass(double* Px, double* Py, double* Pz, unsign
 // A spawn node must exist and have an out-edge (map.py:62-64 re-draws otherwise; the host RNG mirror
 // does that).  Anything else would index out of bounds, so it is replaced and flagged.
 __device__ inline int checked_spawn(const DevMap& m, int node, int& status) {
-  if ((unsigned)node < (unsigned)m.lpN && m.next_off[node + 1] > m.next_off[node]) return node;
+  if ((unsigned)node < (unsigned)m.lpN && m.lp_fat[node].nnext > 0) return node;
   status |= TC_S_BAD_SPAWN;
   return m.first_spawnable;
 }
 
 __device__ inline unsigned int spread4(unsigned int x) {  // x < 16: 4 bits -> 4 bytes of 0x00/0xFF
-  return ((x * 0x00204081u) & 0x01010101u) * 255u;
+  const unsigned int m = (x * 0x00204081u) & 0x01010101u;  // 24-bit multiply: full rate
+  return (m << 8) - m;                                     // * 255 without v_mul_lo_u32
 }
 
 // camera.py:133-142 for one node + the np.int32 cast of renderer.py:43,50
@@ -187,6 +188,9 @@ __global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, in
   s.last_maneuver = b.last_maneuver[env];
 
   int status = 0, trunc = 0;
+  PathInfo pinfo;
+  pinfo.ax = pinfo.ay = pinfo.bx = pinfo.by = pinfo.ori = 0;
+  pinfo.valid = 0;
   bool fresh = false;  // env was (re)spawned in this launch: info is empty (car.py:47-51)
   if (mode == MODE_RESET) {
     d_reset(m, a.car, s, checked_spawn(m, spawn_nodes[env], status));
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, in
       }
       v = d_np_clip(v, -1.0, 1.0);  // env.py:118
       st = d_np_clip(st, -1.0, 1.0);
-      trunc = d_car_step(m, a.car, s, v, st, maneuver[env], status);
+      trunc = d_car_step(m, a.car, s, v, st, maneuver[env], status, pinfo);
     }
   }
 
@@ -220,10 +224,17 @@ __global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, in
     // ---- write the state back + scalar info (lane 0)
     const bool have_info = !fresh && s.lp_len >= 2;
     double cte = 0, he = 0;
-    if (have_info) {  // car.py:52-53
+    if (have_info && !pinfo.valid) {  // path kept from an earlier step (truncated before it was rebuilt)
       double2 n1 = m.lp_nodes[s.lp[2]], n2 = m.lp_nodes[s.lp[3]];
-      cte = d_distance_to_edge(n1.x, n1.y, n2.x, n2.y, s.front_x, s.front_y);
-      he = d_clip_angle(d_lp_edge_ori(m, s.lp[2], s.lp[3]) - s.theta);
+      pinfo.ax = n1.x;
+      pinfo.ay = n1.y;
+      pinfo.bx = n2.x;
+      pinfo.by = n2.y;
+      pinfo.ori = d_lp_edge_ori(m, s.lp[2], s.lp[3]);
+    }
+    if (have_info) {  // car.py:52-53 (nodes and orientation of local_path[1] were captured while tracking)
+      cte = d_distance_to_edge(pinfo.ax, pinfo.ay, pinfo.bx, pinfo.by, s.front_x, s.front_y);
+      he = d_clip_angle(pinfo.ori - s.theta);
     }
     double reward = 0;
     int terminated = 0;
@@ -422,10 +433,14 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
   unsigned char* out = a.obs + (size_t)env * ((size_t)H * W * (FMT == TC_FMT_CLASSES ? C : 3));
   int* lt = (int*)(smem + a.off_tab);     // [RB*4][5] outline-edge parameters
   int* lc = lt + RB * 4 * 5;              // [RB*4] chunks per outline edge, then exclusive prefix
-  int* fl = lc + RB * 4;                  // [RB] first fill row
-  int* fh = fl + RB;                      // [RB] last fill row
-  int* fc = fh + RB;                      // [RB] fill chunks, then exclusive prefix
-  int* fd = fc + RB;                      // [RB][2] ThickLine's (dp.x, dp.y) of the segment
+  int* fl = lc + RB * 4;                  // [RB] first fill row of the segment in this band
+  int* fc = fl + RB;                      // [RB] fill rows, then exclusive prefix
+  int* fm = fc + RB;                      // [RB] pieces | walker mask << 8 | quad valid << 16
+  int* fd = fm + RB;                      // [RB][2] ThickLine's (dp.x, dp.y)
+  int* fpy = fd + 2 * RB;                 // [RB][4] fill pieces: start row
+  int* fpv = fpy + 4 * RB;                // [RB][4] fill pieces: polygon vertices idx0 | idx << 2
+  long long* fpx = (long long*)(fpv + 4 * RB);  // [RB][4] x at the start row (16.16)
+  long long* fpd = fpx + 4 * RB;          // [RB][4] dx per row
   for (int band = 0; band < cam.n_bands; band++) {
     const int y0 = band * cam.band_rows;
     const int y1 = (y0 + cam.band_rows < H) ? y0 + cam.band_rows : H;
@@ -449,54 +464,67 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
       }
     } else {
       // ThickLine = FillConvexPoly(quad) [4 Line2 outline edges + scanline fill] + 2 round caps.
-      // Segments are taken RB at a time; their pixel work is cut into small uniform chunks that are
-      // dealt to the 64 lanes through prefix sums, so one long line does not serialise the wave.
+      // Segments are taken RB at a time; their pixel work is cut into small uniform items that are dealt
+      // to the 64 lanes through prefix sums, so one long line does not serialise the wave.
       for (int base = 0; base < nseg; base += RB) {
         const int nb = nseg - base < RB ? nseg - base : RB;
-        for (int t = tid; t < RB * 4; t += TC_NT) {  // outline edges: clip + DDA parameters
-          int nchunk = 0;
-          if (t < nb * 4) {
-            const int k = base + (t >> 2), e = t & 3;
-            const int* sg = segg + 5 * k;
-            long long qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3;
-            if (r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
-              // FillConvexPoly walks p0 = v[3]; Line2(p0, v[i]); p0 = v[i]
-              long long ax = sel4(qx3, qx0, qx1, qx2, e), ay = sel4(qy3, qy0, qy1, qy2, e);
-              long long bx = sel4(qx0, qx1, qx2, qx3, e), by = sel4(qy0, qy1, qy2, qy3, e);
-              LineP L = r_line2_setup(W, H, ax, ay, bx, by);
-              if (L.ecount >= 0) {
-                r.bits = bits + sg[0] * plane;
-                r_put(r, L.ex, L.ey);
-                int* o = lt + 5 * t;
-                o[0] = L.a;
-                o[1] = L.b;
-                o[2] = L.step;
-                o[3] = L.ecount | (L.xmajor << 30);
-                o[4] = sg[0];
-                nchunk = (L.ecount + LCH) / LCH;
-              }
-            }
-          }
-          lc[t] = nchunk;
-        }
-        if (tid < RB) {  // fill rows of this band
-          int nchunk = 0, lo = 0, hi = -1;
+        if (tid < RB) {  // per segment: ThickLine's dp, fill walker pieces, fill rows of this band
+          int nrow = 0, lo = 0, np = 0, wm = 0, dpx = 0, dpy = 0, okq = 0;
           if (tid < nb) {
-            const int k = base + tid;
-            const int* sg = segg + 5 * k;
+            const int* sg = segg + 5 * (base + tid);
             long long qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3;
             if (r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
-              r_fill_row_range(W, H, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, lo, hi);
+              okq = 1;
+              dpx = (int)(qx0 - (long long)sg[1] * TC_XY_ONE);
+              dpy = (int)(qy0 - (long long)sg[2] * TC_XY_ONE);
+              int hi;
+              np = r_fill_events(W, H, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, fpy + 4 * tid, fpv + 4 * tid, wm, lo,
+                                 hi);
               if (lo < y0) lo = y0;
               if (hi > y1 - 1) hi = y1 - 1;
-              if (hi >= lo) nchunk = (hi - lo + FCH) / FCH;
-              fd[2 * tid] = (int)(qx0 - (long long)sg[1] * TC_XY_ONE);      // dp.x
-              fd[2 * tid + 1] = (int)(qy0 - (long long)sg[2] * TC_XY_ONE);  // dp.y
+              if (np > 0 && hi >= lo) nrow = hi - lo + 1;
             }
           }
           fl[tid] = lo;
-          fh[tid] = hi;
-          fc[tid] = nchunk;
+          fc[tid] = nrow;
+          fm[tid] = np | (wm << 8) | (okq << 16);
+          fd[2 * tid] = dpx;
+          fd[2 * tid + 1] = dpy;
+        }
+        __syncthreads();
+        for (int t = tid; t < RB * 4; t += TC_NT) {  // outline edges: clip + DDA parameters
+          int nchunk = 0;
+          if (t < nb * 4 && ((fm[t >> 2] >> 16) & 1)) {
+            const int j = t >> 2, e = t & 3;
+            const int* sg = segg + 5 * (base + j);
+            const long long p0x = (long long)sg[1] * TC_XY_ONE, p0y = (long long)sg[2] * TC_XY_ONE;
+            const long long p1x = (long long)sg[3] * TC_XY_ONE, p1y = (long long)sg[4] * TC_XY_ONE;
+            const long long dpx = fd[2 * j], dpy = fd[2 * j + 1];
+            const long long qx0 = p0x + dpx, qx1 = p0x - dpx, qx2 = p1x - dpx, qx3 = p1x + dpx;
+            const long long qy0 = p0y + dpy, qy1 = p0y - dpy, qy2 = p1y - dpy, qy3 = p1y + dpy;
+            // FillConvexPoly walks p0 = v[3]; Line2(p0, v[i]); p0 = v[i]
+            long long ax = sel4(qx3, qx0, qx1, qx2, e), ay = sel4(qy3, qy0, qy1, qy2, e);
+            long long bx = sel4(qx0, qx1, qx2, qx3, e), by = sel4(qy0, qy1, qy2, qy3, e);
+            if (e < (fm[j] & 0xff)) {  // fill piece e of this segment: x at its start row and slope
+              long long xs, dxs;
+              r_fill_slope(qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, fpy[t], fpv[t], xs, dxs);
+              fpx[t] = xs;
+              fpd[t] = dxs;
+            }
+            LineP L = r_line2_setup(W, H, ax, ay, bx, by);
+            if (L.ecount >= 0) {
+              r.bits = bits + sg[0] * plane;
+              r_put(r, L.ex, L.ey);
+              int* o = lt + 5 * t;
+              o[0] = L.a;
+              o[1] = L.b;
+              o[2] = L.step;
+              o[3] = L.ecount | (L.xmajor << 30);
+              o[4] = sg[0];
+              nchunk = (L.ecount + LCH) / LCH;
+            }
+          }
+          lc[t] = nchunk;
         }
         __syncthreads();
         int tot_l, tot_f;
@@ -525,23 +553,16 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
           r.bits = bits + o[4] * plane;
           r_line2_pixels(r, o[0], o[1], o[2], xmajor, k0, k1);
         }
-        for (int c = tid; c < tot_f && !(a.flags & DBG_SKIP_R3); c += TC_NT) {  // scanline fill, FCH rows per chunk
+        for (int c = tid; c < tot_f && !(a.flags & DBG_SKIP_R3); c += TC_NT) {  // scanline fill, one row per item
           int lo = 0, hi = RB;
           while (hi - lo > 1) {
             int mid = (lo + hi) >> 1;
             if (fc[mid] <= c) lo = mid; else hi = mid;
           }
-          const int k = base + lo;
-          const int* sg = segg + 5 * k;
-          const long long p0x = (long long)sg[1] * TC_XY_ONE, p0y = (long long)sg[2] * TC_XY_ONE;
-          const long long p1x = (long long)sg[3] * TC_XY_ONE, p1y = (long long)sg[4] * TC_XY_ONE;
-          const long long dpx = fd[2 * lo], dpy = fd[2 * lo + 1];
-          const long long qx0 = p0x + dpx, qx1 = p0x - dpx, qx2 = p1x - dpx, qx3 = p1x + dpx;
-          const long long qy0 = p0y + dpy, qy1 = p0y - dpy, qy2 = p1y - dpy, qy3 = p1y + dpy;
-          const int row_lo = fl[lo] + (c - fc[lo]) * FCH;
-          const int row_hi = row_lo + FCH < fh[lo] + 1 ? row_lo + FCH : fh[lo] + 1;
-          r.bits = bits + sg[0] * plane;
-          r_fill_rows(r, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, row_lo, row_hi);
+          const int row = fl[lo] + (c - fc[lo]);
+          const int mm = fm[lo];
+          r.bits = bits + segg[5 * (base + lo)] * plane;
+          r_fill_row(r, row, mm & 0xff, (mm >> 8) & 0xff, fpy + 4 * lo, fpx + 4 * lo, fpd + 4 * lo);
         }
         for (int t = tid; t < nb * 2 && !(a.flags & DBG_SKIP_R4); t += TC_NT) {  // round caps (flags = 3: both ends)
           const int k = base + (t >> 1);
@@ -559,24 +580,31 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
     __syncthreads();
     if (a.flags & DBG_SKIP_STORE) {
     } else if (FMT == TC_FMT_CLASSES) {
-      if ((W & 15) == 0) {
+      if (false) {
+      } else if ((W & 15) == 0) {
         // 16 pixels -> one 16-byte store per lane, consecutive lanes on consecutive addresses
-        const int g = W >> 4;                            // 16-pixel groups per row
-        const int gs = (g & (g - 1)) == 0 ? __ffs(g) - 1 : -1;
+        // (two 16-byte stores per lane at a 32-byte lane stride were tried: 2x slower, half-line writes)
+        const int g = W >> 4;  // 16-pixel groups per row
         const int per_plane = rows * g;
+        const bool dense = (W & 31) == 0;  // then 16-bit half h of plane word q>>1 is group q
         for (int c = 0; c < C; c++) {
           const unsigned int* pl = bits + c * cam.band_rows * wpr;
           unsigned char* po = out + ((size_t)c * H + y0) * W;
           for (int q = tid; q < per_plane; q += TC_NT) {
-            const int yy = gs >= 0 ? q >> gs : q / g;
-            const int xx = (q - yy * g) << 4;
-            const unsigned int b16 = (pl[yy * wpr + (xx >> 5)] >> (xx & 31)) & 0xffffu;
+            unsigned int b16;
+            if (dense) {
+              b16 = (pl[q >> 1] >> ((q & 1) << 4)) & 0xffffu;
+            } else {
+              const int yy = q / g;
+              const int xx = (q - yy * g) << 4;
+              b16 = (pl[yy * wpr + (xx >> 5)] >> (xx & 31)) & 0xffffu;
+            }
             uint4 o;
             o.x = spread4(b16 & 15u);
             o.y = spread4((b16 >> 4) & 15u);
             o.z = spread4((b16 >> 8) & 15u);
             o.w = spread4(b16 >> 12);
-            *(uint4*)(po + (size_t)q * 16) = o;  // rows of a plane are contiguous: group q sits at byte 16 q
+            *(uint4*)(po + (size_t)q * 16) = o;
           }
         }
       } else {
@@ -772,6 +800,21 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
       pori[p] = atan2(lpn[a].y - lpn[b].y, lpn[a].x - lpn[b].x);  // layer.py:122 seen from b
     }
   }
+  std::vector<LpNode> fat(lpN);
+  for (int i = 0; i < lpN; i++) {
+    LpNode& F = fat[i];
+    memset(&F, 0, sizeof(F));
+    F.x = lpn[i].x;
+    F.y = lpn[i].y;
+    F.nnext = noff[i + 1] - noff[i];
+    F.nprev = poff[i + 1] - poff[i];
+    for (int k = 0; k < 3; k++) {
+      F.next[k] = k < F.nnext ? nnode[noff[i] + k] : -1;
+      F.next_ori[k] = k < F.nnext ? nori[noff[i] + k] : 0.0;
+      F.prev[k] = k < F.nprev ? pnode[poff[i] + k] : -1;
+      F.prev_ori[k] = k < F.nprev ? pori[poff[i] + k] : 0.0;
+    }
+  }
   d.lpN = lpN;
   d.lpE = lpE;
   d.first_spawnable = -1;
@@ -786,7 +829,7 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
   HIP_TRY(hipGetDevice(&m->device));
 #define UP(vec, field)                                             \
   if (rc == TC_OK) rc = upload(m, vec, &d.field);
-  UP(nodes, nodes) UP(edges, edges) UP(edges_g, edges_g) UP(edge_layer, edge_layer) UP(of, ori_fwd) UP(orv, ori_rev) UP(lpn, lp_nodes) UP(lpe, lp_edges)
+  UP(fat, lp_fat) UP(nodes, nodes) UP(edges, edges) UP(edges_g, edges_g) UP(edge_layer, edge_layer) UP(of, ori_fwd) UP(orv, ori_rev) UP(lpn, lp_nodes) UP(lpe, lp_edges)
   UP(lpo, lp_ori) UP(noff, next_off) UP(nnode, next_node) UP(nori, next_ori) UP(poff, prev_off)
   UP(pnode, prev_node) UP(pori, prev_ori)
 #undef UP
@@ -873,7 +916,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   L.total = off;
   // raster kernel: tables + bit-planes of one band
   e->r_off_tab = 0;
-  e->r_off_bits = align_up((RB * 4 * 5 + RB * 4 + 5 * RB) * 4, 16);
+  e->r_off_bits = align_up((RB * 4 * 5 + RB * 4 + 5 * RB + 8 * RB) * 4 + 2 * 4 * RB * 8, 16);
   e->r_lds = e->r_off_bits + align_up(m.C * band_rows * dc.wpr * 4, 16);
   if (L.total > 160 * 1024 || e->r_lds > 160 * 1024) {
     set_err("tc_env_create: map too large for one workgroup's LDS");
