@@ -65,6 +65,19 @@ def gen_actions(n_envs, n_steps, seed, device):
     return cc, man
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
+    (profiles/r01/<workload>_pmc.json: separate --pmc FETCH_SIZE and WRITE_SIZE passes; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950), or None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", f"{workload}_pmc.json")
+    try:
+        with open(path) as f:
+            j = json.load(f)
+        return sum((2 * j[k]["FETCH_SIZE"] + j[k]["WRITE_SIZE"]) * 1024.0 for k in kernel.split("+"))
+    except Exception:
+        return None
+
+
 def host_cores():
     """Host threads this process may really use: cgroup cpu quota if there is one, else the affinity mask,
     capped at 16 (the CPU share of a one-GPU box)."""
@@ -166,6 +179,7 @@ def main():
                 gather.step()
 
     run(0, W)
+    env.profile(8)  # HIP events around both kernels of every 8th timed step (every step would serialise the queue)
     if gather is not None:
         gather.wait()
     if dist is not None:
@@ -193,8 +207,16 @@ def main():
     H, Wd = env.camera.resolution
     b_obs = 0 if w["no_obs"] else (C * H * Wd if w["fmt"] == "classes" else 3 * H * Wd)
     bytes_per_env_step = B_STATE + b_obs
-    kernel_s = ev_ms / 1e3 / K  # HIP events on the launch stream around the K timed launches
-    achieved = bytes_per_env_step * n / kernel_s / 1e9
+    step_s = ev_ms / 1e3 / K  # HIP events on the launch stream around the K timed steps (both kernels)
+    prof = env.profile_read()  # per-kernel HIP events sampled over the timed region
+    # One step = two back-to-back kernels of similar length (simulate: state/action/info, 240 B per env;
+    # raster: the observation, written once).  The roofline unit is therefore the step: SURVEY 8d's
+    # algorithmic bytes per env-step x envs per launch, divided by the summed kernel durations.
+    kname = "tc_env_kernel+tc_raster_kernel" if b_obs else "tc_env_kernel"
+    kernel_s = (prof["simulate_us"] + (prof["raster_us"] if b_obs else 0.0)) * 1e-6
+    kbytes = bytes_per_env_step * n
+    achieved = kbytes / kernel_s / 1e9
+    traffic = pmc_traffic(args.workload, kname) if n == WORKLOADS[args.workload]["envs"] else None
     out = {
         "metric": "env-steps/sec (whole node)",
         "value": world * n * K / dt,
@@ -214,9 +236,14 @@ def main():
                    "autoreset": True, "resets_in_run": n_resets, "gather": args.gather if world > 1 else "n/a",
                    "lds_bytes_per_env": env.lds_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "tc_env_kernel", "kernel_us": kernel_s * 1e6,
-                     "algorithmic_bytes_per_launch": bytes_per_env_step * n},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": kname, "kernel_us": kernel_s * 1e6, "algorithmic_bytes_per_launch": kbytes,
+                     "kernels_us": {"tc_env_kernel": prof["simulate_us"], "tc_raster_kernel": prof["raster_us"]},
+                     "event_samples": prof["launches"],
+                     "step_us": step_s * 1e6, "step_algorithmic_bytes": bytes_per_env_step * n,
+                     "step_achieved_GBs": bytes_per_env_step * n / step_s / 1e9,
+                     "traffic_source": "profiles/r01 rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                       "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)" if traffic else None},
     }
     if rank == 0:
         if not args.no_cpu_baseline:

@@ -149,6 +149,13 @@ int64_t tc_env_obs_bytes(const tc_env* env);
 /* dynamic LDS bytes one workgroup of the step kernel uses (for occupancy reporting) */
 int64_t tc_env_lds_bytes(const tc_env* env);
 
+/* Per-kernel timing for benchmarks: with enable = n > 0 every n-th tc_step records HIP events on the caller's
+ * stream around its two kernels ("simulate": kinematics + tracking + distances + camera geometry; "raster":
+ * cv2.polylines + observation store) into a ring of the last 64 launches.  tc_env_profile_read waits for
+ * those launches and returns their mean durations in microseconds. */
+int tc_env_profile(tc_env* env, int32_t enable);
+int tc_env_profile_read(tc_env* env, double* simulate_us, double* raster_us, int32_t* launches);
+
 /* env.py:101-113 for the envs selected by mask (NULL = all): pose from spawn_nodes[i], zeroed info,
  * observation rendered unless TC_F_NO_OBSERVATION. */
 int tc_reset(tc_env* env, const int32_t* spawn_nodes, const uint8_t* mask, uint32_t flags, void* stream);

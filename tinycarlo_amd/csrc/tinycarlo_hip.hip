@@ -21,6 +21,7 @@
 #include "../../include/tinycarlo_hip.h"
 #include "tc_device.h"
 
+#define TC_PROF_RING 64
 #define MODE_STEP 0
 #define MODE_RESET 1
 #define MODE_RENDER 2
@@ -619,7 +620,36 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
       }
     } else {
       // rgb: painter's order (renderer.py:41-43): the highest layer covering a pixel wins
-      if ((W & 3) == 0) {
+      if ((W & 15) == 0) {
+        // Lane lines cover ~1 % of an rgb frame.  Write the band as zeros with coalesced 16-byte stores,
+        // then revisit only the pixels that have a bit set in some plane (byte stores into lines this
+        // wavefront has just written).
+        const int n16 = rows * W * 3 / 16;
+        uint4* dst = (uint4*)(out + (size_t)y0 * W * 3);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int q = tid; q < n16; q += TC_NT) dst[q] = z;
+        __syncthreads();  // vmcnt(0): the zeros are in the memory system before the sparse stores are issued
+        const int nw = rows * wpr;
+        for (int q = tid; q < nw; q += TC_NT) {
+          unsigned int any = 0;
+          for (int c = 0; c < C; c++) any |= bits[c * cam.band_rows * wpr + q];
+          if (any == 0) continue;
+          const int yy = q / wpr, xw = (q - yy * wpr) << 5;
+          unsigned char* row = out + ((size_t)(y0 + yy) * W + xw) * 3;
+          while (any) {
+            const int bpos = __ffs(any) - 1;
+            any &= any - 1;
+            int top = 0;
+            for (int c = 1; c < C; c++)
+              if ((bits[c * cam.band_rows * wpr + q] >> bpos) & 1u) top = c;
+            // `any` has the bit, so some plane has it; plane 0 is the default when no higher one does
+            unsigned char* o = row + bpos * 3;
+            o[0] = a.colors[top][0];
+            o[1] = a.colors[top][1];
+            o[2] = a.colors[top][2];
+          }
+        }
+      } else if ((W & 3) == 0) {
         const int total = rows * W / 4;
         for (int g = tid; g < total; g += TC_NT) {
           int pix = g * 4;
@@ -692,6 +722,11 @@ struct tc_env {
   bool bound;
   int64_t obs_bytes;
   int r_off_tab, r_off_bits, r_lds;
+  // optional per-kernel timing: a ring of (start, mid, end) HIP events recorded on the caller's stream
+  int prof;    // 0 = off, n = record every n-th tc_step
+  int prof_n;  // launches recorded so far
+  int prof_calls;
+  hipEvent_t ev[3][TC_PROF_RING];
 };
 
 template <typename T>
@@ -870,6 +905,10 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   memset(&e->k, 0, sizeof(e->k));
   e->map = map;
   e->bound = false;
+  e->prof = 0;
+  e->prof_n = 0;
+  e->prof_calls = 0;
+  memset(e->ev, 0, sizeof(e->ev));
   e->k.m = map->d;
   e->k.N = num_envs;
   DevCar& c = e->k.car;
@@ -957,7 +996,40 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   return TC_OK;
 }
 
+extern "C" int tc_env_profile(tc_env* e, int32_t enable) {
+  if (!e) return TC_E_INVALID;
+  if (enable && !e->ev[0][0]) {
+    for (int k = 0; k < 3; k++)
+      for (int i = 0; i < TC_PROF_RING; i++) HIP_TRY(hipEventCreate(&e->ev[k][i]));
+  }
+  e->prof = enable > 0 ? enable : 0;
+  e->prof_n = 0;
+  e->prof_calls = 0;
+  return TC_OK;
+}
+
+extern "C" int tc_env_profile_read(tc_env* e, double* sim_us, double* raster_us, int32_t* launches) {
+  if (!e || !sim_us || !raster_us || !launches) return TC_E_INVALID;
+  int n = e->prof_n < TC_PROF_RING ? e->prof_n : TC_PROF_RING;
+  double a = 0, b = 0;
+  for (int i = 0; i < n; i++) {
+    float t0 = 0, t1 = 0;
+    HIP_TRY(hipEventSynchronize(e->ev[2][i]));
+    HIP_TRY(hipEventElapsedTime(&t0, e->ev[0][i], e->ev[1][i]));
+    HIP_TRY(hipEventElapsedTime(&t1, e->ev[1][i], e->ev[2][i]));
+    a += t0;
+    b += t1;
+  }
+  *launches = n;
+  *sim_us = n ? a / n * 1e3 : 0;
+  *raster_us = n ? b / n * 1e3 : 0;
+  return TC_OK;
+}
+
 extern "C" int tc_env_destroy(tc_env* e) {
+  if (e && e->ev[0][0])
+    for (int k = 0; k < 3; k++)
+      for (int i = 0; i < TC_PROF_RING; i++) (void)hipEventDestroy(e->ev[k][i]);
   if (e && e->k.seg_g) (void)hipFree(e->k.seg_g);
   if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
   delete e;
@@ -1008,9 +1080,13 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     set_err("TC_F_AUTORESET needs needs_reset/spawn_queue/spawn_cursor buffers");
     return TC_E_INVALID;
   }
+  const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;
+  const int slot = e->prof_n % TC_PROF_RING;
+  if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], (hipStream_t)stream));
   hipLaunchKernelGGL(tc_env_kernel, dim3(e->k.N), dim3(TC_NT), e->k.lds.total, (hipStream_t)stream, e->k, mode, cc,
                      cdtype, man, spawn, mask, flags);
   HIP_TRY(hipGetLastError());
+  if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], (hipStream_t)stream));
   if (!(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs) {
     RArgs r;
     memset(&r, 0, sizeof(r));
@@ -1051,6 +1127,10 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
                       : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
     hipLaunchKernelGGL(kern, dim3(e->k.N), dim3(TC_NT), e->r_lds, (hipStream_t)stream, r);
     HIP_TRY(hipGetLastError());
+  }
+  if (prof) {
+    HIP_TRY(hipEventRecord(e->ev[2][slot], (hipStream_t)stream));
+    e->prof_n++;
   }
   return TC_OK;
 }

@@ -245,6 +245,15 @@ class TinyCarloVecEnv(gym.Env):
                                         self._stream()), "tc_step")
         self._keep = (car_control, maneuver)
 
+    def profile(self, every: int = 1) -> None:
+        """Record HIP events around the two kernels of every `every`-th step (ring of the last 64 samples); 0 = off."""
+        nat.check(nat.lib().tc_env_profile(self._h, int(every)), "tc_env_profile")
+
+    def profile_read(self) -> Dict[str, float]:
+        a, b, n = C.c_double(), C.c_double(), C.c_int32()
+        nat.check(nat.lib().tc_env_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "tc_env_profile_read")
+        return {"simulate_us": a.value, "raster_us": b.value, "launches": n.value}
+
     def render_current(self) -> None:
         """Camera.capture_frame of the current state into self.out["obs"], no step (camera.py:52)."""
         with torch.cuda.device(self.device):
