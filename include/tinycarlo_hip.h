@@ -165,6 +165,11 @@ int tc_reset(tc_env* env, const int32_t* spawn_nodes, const uint8_t* mask, uint3
 int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const int32_t* maneuver, uint32_t flags,
             void* stream);
 
+/* Renderer.render_camera_frame_{rgb,classes} alone (renderer.py:36-51): rasterise caller-provided segment lists
+ * into the bound observation tensor.  segments: device int32 [N][capacity][5] rows of (layer, x0, y0, x1, y1) --
+ * the np.int32 end points handed to cv2.polylines; counts: device int32 [N], each <= capacity. */
+int tc_render_segments(tc_env* env, const int32_t* segments, const int32_t* counts, int32_t capacity, void* stream);
+
 /* Re-render the observation of the current state without stepping (Camera.capture_frame, camera.py:52). */
 int tc_render(tc_env* env, uint32_t flags, void* stream);
 

@@ -25,7 +25,7 @@ S_UTURN_NO_EDGE, S_PICK_EMPTY, S_BAD_SPAWN, S_NOT_RESET = 1, 2, 4, 8
 
 EXPORTS = ["tc_abi_version", "tc_last_error", "tc_map_create", "tc_map_destroy", "tc_env_create", "tc_env_destroy",
            "tc_env_bind", "tc_env_set_camera", "tc_env_obs_bytes", "tc_env_lds_bytes", "tc_env_profile",
-           "tc_env_profile_read", "tc_reset", "tc_step", "tc_render"]
+           "tc_env_profile_read", "tc_reset", "tc_step", "tc_render", "tc_render_segments"]
 
 _dp, _ip, _bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 
@@ -98,6 +98,7 @@ def lib():
     L.tc_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.tc_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.tc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.tc_render_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     if L.tc_abi_version() != ABI_VERSION:
         raise NativeError(f"ABI mismatch: library {L.tc_abi_version()} vs binding {ABI_VERSION}")
     _lib = L

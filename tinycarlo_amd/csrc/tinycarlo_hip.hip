@@ -429,6 +429,10 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
   unsigned int* bits = (unsigned int*)(smem + a.off_bits);
   const int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;
   const int nseg = a.seg_n[env];
+  unsigned int used_layers = 0;  // layers that have at least one segment in this frame (wave-uniform)
+  for (int k = tid; k < nseg; k += TC_NT) used_layers |= 1u << segg[5 * k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) used_layers |= __shfl_xor(used_layers, off);
 
   const int H = cam.H, W = cam.W, wpr = cam.wpr, C = a.C;
   unsigned char* out = a.obs + (size_t)env * ((size_t)H * W * (FMT == TC_FMT_CLASSES ? C : 3));
@@ -588,9 +592,14 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
         const int g = W >> 4;  // 16-pixel groups per row
         const int per_plane = rows * g;
         const bool dense = (W & 31) == 0;  // then 16-bit half h of plane word q>>1 is group q
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
         for (int c = 0; c < C; c++) {
           const unsigned int* pl = bits + c * cam.band_rows * wpr;
           unsigned char* po = out + ((size_t)c * H + y0) * W;
+          if (!((used_layers >> c) & 1u)) {  // no segment of this layer in the frame: the plane is all zeros
+            for (int q = tid; q < per_plane; q += TC_NT) *(uint4*)(po + (size_t)q * 16) = zero4;
+            continue;
+          }
           for (int q = tid; q < per_plane; q += TC_NT) {
             unsigned int b16;
             if (dense) {
@@ -600,12 +609,14 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
               const int xx = (q - yy * g) << 4;
               b16 = (pl[yy * wpr + (xx >> 5)] >> (xx & 31)) & 0xffffu;
             }
-            uint4 o;
-            o.x = spread4(b16 & 15u);
-            o.y = spread4((b16 >> 4) & 15u);
-            o.z = spread4((b16 >> 8) & 15u);
-            o.w = spread4(b16 >> 12);
-            *(uint4*)(po + (size_t)q * 16) = o;
+            uint4 o = zero4;
+            if (__ballot(b16 != 0)) {  // wave-uniform: skip the bit spreading when all 64 groups are empty
+              o.x = spread4(b16 & 15u);
+              o.y = spread4((b16 >> 4) & 15u);
+              o.z = spread4((b16 >> 8) & 15u);
+              o.w = spread4(b16 >> 12);
+            }
+            *(uint4*)(po + (size_t)q * 16) = o;  // rows of a plane are contiguous: group q sits at byte 16 q
           }
         }
       } else {
@@ -1069,25 +1080,9 @@ extern "C" int tc_env_set_camera(tc_env* e, const tc_camera_params* cam) {
   return rc;
 }
 
-static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t* man, const int32_t* spawn,
-                  const uint8_t* mask, uint32_t flags, void* stream) {
-  if (!e) return TC_E_INVALID;
-  if (!e->bound) {
-    set_err("tc_env_bind has not been called");
-    return TC_E_UNBOUND;
-  }
-  if ((flags & TC_F_AUTORESET) && !e->k.b.needs_reset) {
-    set_err("TC_F_AUTORESET needs needs_reset/spawn_queue/spawn_cursor buffers");
-    return TC_E_INVALID;
-  }
-  const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;
-  const int slot = e->prof_n % TC_PROF_RING;
-  if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], (hipStream_t)stream));
-  hipLaunchKernelGGL(tc_env_kernel, dim3(e->k.N), dim3(TC_NT), e->k.lds.total, (hipStream_t)stream, e->k, mode, cc,
-                     cdtype, man, spawn, mask, flags);
-  HIP_TRY(hipGetLastError());
-  if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], (hipStream_t)stream));
-  if (!(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs) {
+static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
+                         void* stream) {
+  {
     RArgs r;
     memset(&r, 0, sizeof(r));
     r.N = e->k.N;
@@ -1114,11 +1109,11 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       }
     }
     memcpy(r.colors, e->k.m.colors, sizeof(r.colors));
-    r.seg_g = e->k.seg_g;
-    r.seg_n = e->k.seg_n;
-    r.seg_cap = e->k.seg_cap;
+    r.seg_g = seg_g;
+    r.seg_n = seg_n;
+    r.seg_cap = seg_cap;
     r.obs = e->k.b.obs;
-    r.mask = mode == MODE_RESET ? mask : nullptr;
+    r.mask = mask;
     r.off_tab = e->r_off_tab;
     r.off_bits = e->r_off_bits;
     r.flags = flags;
@@ -1127,6 +1122,31 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
                       : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
     hipLaunchKernelGGL(kern, dim3(e->k.N), dim3(TC_NT), e->r_lds, (hipStream_t)stream, r);
     HIP_TRY(hipGetLastError());
+  }
+  return TC_OK;
+}
+
+static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t* man, const int32_t* spawn,
+                  const uint8_t* mask, uint32_t flags, void* stream) {
+  if (!e) return TC_E_INVALID;
+  if (!e->bound) {
+    set_err("tc_env_bind has not been called");
+    return TC_E_UNBOUND;
+  }
+  if ((flags & TC_F_AUTORESET) && !e->k.b.needs_reset) {
+    set_err("TC_F_AUTORESET needs needs_reset/spawn_queue/spawn_cursor buffers");
+    return TC_E_INVALID;
+  }
+  const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;
+  const int slot = e->prof_n % TC_PROF_RING;
+  if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], (hipStream_t)stream));
+  hipLaunchKernelGGL(tc_env_kernel, dim3(e->k.N), dim3(TC_NT), e->k.lds.total, (hipStream_t)stream, e->k, mode, cc,
+                     cdtype, man, spawn, mask, flags);
+  HIP_TRY(hipGetLastError());
+  if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], (hipStream_t)stream));
+  if (!(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs) {
+    int rc = launch_raster(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, mode == MODE_RESET ? mask : nullptr, flags, stream);
+    if (rc != TC_OK) return rc;
   }
   if (prof) {
     HIP_TRY(hipEventRecord(e->ev[2][slot], (hipStream_t)stream));
@@ -1144,6 +1164,16 @@ extern "C" int tc_step(tc_env* e, const void* car_control, int32_t control_dtype
                        uint32_t flags, void* stream) {
   if (!car_control || !maneuver || (control_dtype != TC_F32 && control_dtype != TC_F64)) return TC_E_INVALID;
   return launch(e, MODE_STEP, car_control, control_dtype, maneuver, nullptr, nullptr, flags, stream);
+}
+
+extern "C" int tc_render_segments(tc_env* e, const int32_t* segments, const int32_t* counts, int32_t capacity,
+                                  void* stream) {
+  if (!e || !segments || !counts || capacity < 1) return TC_E_INVALID;
+  if (!e->bound || !e->k.b.obs) {
+    set_err("tc_render_segments needs bound buffers with an observation tensor");
+    return TC_E_UNBOUND;
+  }
+  return launch_raster(e, segments, counts, capacity, nullptr, 0, stream);
 }
 
 extern "C" int tc_render(tc_env* e, uint32_t flags, void* stream) {

@@ -259,6 +259,17 @@ class TinyCarloVecEnv(gym.Env):
         with torch.cuda.device(self.device):
             nat.check(nat.lib().tc_render(self._h, 0, self._stream()), "tc_render")
 
+    def render_segments(self, segments: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+        """Renderer.render_camera_frame_{rgb,classes} (renderer.py:36-51) for caller-provided int32 segment lists:
+        segments [N, cap, 5] rows (layer, x0, y0, x1, y1), counts [N].  Returns the observation tensor."""
+        seg = self._to_dev("segments", segments, torch.int32, (self.num_envs, segments.shape[1], 5))
+        cnt = self._to_dev("counts", counts, torch.int32, (self.num_envs,))
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_render_segments(self._h, seg.data_ptr(), cnt.data_ptr(), int(seg.shape[1]),
+                                                   self._stream()), "tc_render_segments")
+        self._keep = (seg, cnt)
+        return self.out["obs"]
+
     def render(self):
         """rgb_array of the class-agnostic camera view is only available in 'rgb' observation format."""
         if self.render_mode == "rgb_array" and self._fmt == nat.FMT_RGB:
