@@ -58,38 +58,73 @@ struct KArgs {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Per-lane register cache of the map: lane `tid` keeps nodes / edges (w*K + k)*64 + tid, k < K, of window w.
+// Maps up to 64*K nodes and edges (all bundled ones with K = 5 or 13) are a single window that is loaded once at
+// kernel start -- behind the latency of phase A -- and then serves every pass of phases B and C; larger maps
+// reload window by window inside each pass.
+template <int K>
+struct MapCache {
+  double2 nd[K];
+  int2 ed[K];
+};
+
+template <int K>
+__device__ inline void cache_nodes(MapCache<K>& c, const DevMap& m, int w) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int i = (w * K + k) * TC_NT + threadIdx.x;
+    c.nd[k] = i < m.total_nodes ? m.nodes[i] : make_double2(0.0, 0.0);
+  }
+}
+template <int K>
+__device__ inline void cache_edges(MapCache<K>& c, const DevMap& m, int w) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int e = (w * K + k) * TC_NT + threadIdx.x;
+    c.ed[k] = e < m.total_edges ? m.edges_g[e] : make_int2(0, 0);
+  }
+}
+
 // camera.py:70-86: one of the four fix-up loops.  `bit` selects the membership flag (1 = idx_front,
 // 2 = idx_in_range).  The reference builds the edge list first and then mutates nodes in list
 // (= edge) order; updates of different target nodes are independent (a target is never read as
 // the "other" end within one pass), so each target node's chain is replayed in ascending edge
-// index by the lane that owns the chain's first edge.
-__device__ inline void cam_fixup_pass(double* Px, double* Py, double* Pz, unsigned char* flg, int bit, const int2* LE,
-                                      int ne, bool target_e0, double tz, int* list, int* cnt) {
+// index by the lane that owns the chain's first edge.  List entries carry (edge, target | other << 16)
+// so the chain loops touch LDS only.
+template <int K>
+__device__ inline void cam_fixup_pass(MapCache<K>& mc, const DevMap& m, bool single, int nwin, double* Px, double* Py,
+                                      double* Pz, unsigned char* flg, int bit, bool target_e0, double tz, int* list,
+                                      int* cnt) {
   const int tid = threadIdx.x;  // *cnt was zeroed (and a barrier passed) before the call
-  for (int e = tid; e < ne; e += TC_NT) {
-    int2 ed = LE[e];
-    bool fa = flg[ed.x] & bit, fb = flg[ed.y] & bit;
-    bool sel = target_e0 ? (!fa && fb) : (fa && !fb);
-    if (sel) list[atomicAdd(cnt, 1)] = e;
+  const int ne = m.total_edges;
+  for (int w = 0; w < nwin; w++) {
+    if (!single) cache_edges(mc, m, w);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int e = (w * K + k) * TC_NT + tid;
+      if (e < ne) {
+        const int2 ed = mc.ed[k];
+        const bool fa = flg[ed.x] & bit, fb = flg[ed.y] & bit;
+        const bool sel = target_e0 ? (!fa && fb) : (fa && !fb);
+        if (sel) {
+          const int j = atomicAdd(cnt, 1);
+          list[2 * j] = e;
+          list[2 * j + 1] = target_e0 ? (ed.x | (ed.y << 16)) : (ed.y | (ed.x << 16));
+        }
+      }
+    }
   }
   __syncthreads();
   const int n = *cnt;
   for (int k = tid; k < n; k += TC_NT) {
-    const int e = list[k];
-    const int t = target_e0 ? LE[e].x : LE[e].y;
+    const int e = list[2 * k];
+    const int t = list[2 * k + 1] & 0xffff;
     bool first = true;
-    for (int j = 0; j < n; j++) {
-      int ej = list[j];
-      int tj = target_e0 ? LE[ej].x : LE[ej].y;
-      if (tj == t && ej < e) {
-        first = false;
-        break;
-      }
-    }
+    for (int j = 0; j < n; j++)
+      if ((list[2 * j + 1] & 0xffff) == t && list[2 * j] < e) first = false;
     if (!first) continue;
-    int cur = e;
+    int cur = e, o = (unsigned)list[2 * k + 1] >> 16;  // the end that stays
     for (int guard = 0; guard < n; guard++) {
-      const int o = target_e0 ? LE[cur].y : LE[cur].x;  // the end that stays
       // camera.py:112-122 __point_on_line_at_z(p0 = P[o], p1 = P[t], tz)
       double d0 = Px[o] - Px[t], d1 = Py[o] - Py[t], d2 = Pz[o] - Pz[t];
       if (d2 == 0) {
@@ -99,19 +134,22 @@ __device__ inline void cam_fixup_pass(double* Px, double* Py, double* Pz, unsign
         Pz[t] = qn;
       } else {
         double tt = (tz - Pz[t]) / d2;
-        double a = Px[t] + tt * d0, b = Py[t] + tt * d1, c = Pz[t] + tt * d2;
-        Px[t] = a;
-        Py[t] = b;
-        Pz[t] = c;
+        double aa = Px[t] + tt * d0, bb = Py[t] + tt * d1, cc = Pz[t] + tt * d2;
+        Px[t] = aa;
+        Py[t] = bb;
+        Pz[t] = cc;
       }
-      int nxt = 0x7fffffff;
+      int nxt = 0x7fffffff, no = 0;
       for (int j = 0; j < n; j++) {
-        int ej = list[j];
-        int tj = target_e0 ? LE[ej].x : LE[ej].y;
-        if (tj == t && ej > cur && ej < nxt) nxt = ej;
+        const int ej = list[2 * j], pj = list[2 * j + 1];
+        if ((pj & 0xffff) == t && ej > cur && ej < nxt) {
+          nxt = ej;
+          no = (unsigned)pj >> 16;
+        }
       }
       if (nxt == 0x7fffffff) break;
       cur = nxt;
+      o = no;
     }
     flg[t] |= (unsigned char)bit;
   }
@@ -154,7 +192,8 @@ __device__ inline int wave_incl_scan(int v) {
 #ifndef TC_MIN_WAVES
 #define TC_MIN_WAVES 4
 #endif
-__global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, int mode, const void* car_control, int cdtype,
+template <int K>
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) void tc_env_kernel(KArgs a, int mode, const void* car_control, int cdtype,
                                                        const int* maneuver, const int* spawn_nodes,
                                                        const unsigned char* mask, unsigned int flags) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -165,6 +204,14 @@ __global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, in
 
   const DevMap& m = a.m;
   const tc_buffers& b = a.b;
+  // map windows of 64*K nodes / edges; one window (the usual case) is fetched now and kept in registers
+  const int nwin_n = (m.total_nodes + TC_NT * K - 1) / (TC_NT * K), nwin_e = (m.total_edges + TC_NT * K - 1) / (TC_NT * K);
+  const bool single = nwin_n <= 1 && nwin_e <= 1;
+  MapCache<K> mc;
+  if (single) {
+    cache_nodes(mc, m, 0);
+    cache_edges(mc, m, 0);
+  }
   double* Px = (double*)(smem + a.lds.off_p);
   double* Py = Px + m.total_nodes;
   double* Pz = Py + m.total_nodes;
@@ -273,22 +320,32 @@ __global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, in
     // ---- phase B: lane-line distances (car.py:55-64)
     const int C = m.C;
     if (have_info && !(flags & DBG_SKIP_DIST)) {
-      for (int i = tid; i < m.total_nodes; i += TC_NT) {
-        double2 n = m.nodes[i];
-        dn[i] = d_dist(s.x, s.y, n.x, n.y);
+      for (int w = 0; w < nwin_n; w++) {
+        if (!single) cache_nodes(mc, m, w);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const int i = (w * K + k) * TC_NT + tid;
+          if (i < m.total_nodes) dn[i] = d_dist(s.x, s.y, mc.nd[k].x, mc.nd[k].y);
+        }
       }
       __syncthreads();
       int my_e = -1;
       for (int l = 0; l < C; l++) {
-        const int no = m.node_off[l], eo = m.edge_off[l], ne = m.edge_off[l + 1] - eo;
+        const int eo = m.edge_off[l], eend = m.edge_off[l + 1];
         int best = -1;
         double bd = 0;
-        for (int e = tid; e < ne; e += TC_NT) {  // layer.py:43
-          int2 ed = m.edges[eo + e];
-          double d = tc_fabs(dn[no + ed.x] + dn[no + ed.y]);
-          if (best < 0 || d < bd) {
-            best = e;
-            bd = d;
+        for (int w = 0; w < nwin_e; w++) {
+          if (!single) cache_edges(mc, m, w);
+#pragma unroll
+          for (int k = 0; k < K; k++) {  // layer.py:43 over this lane's edges of layer l (ascending index)
+            const int e = (w * K + k) * TC_NT + tid;
+            if (e >= eo && e < eend) {
+              double d = tc_fabs(dn[mc.ed[k].x] + dn[mc.ed[k].y]);
+              if (best < 0 || d < bd) {
+                best = e - eo;
+                bd = d;
+              }
+            }
           }
         }
         wave_argmin(bd, best);
@@ -298,9 +355,9 @@ __global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, in
         const int l = tid;
         double dist_l = 0;
         if (my_e >= 0) {
-          const int no = m.node_off[l], ge = m.edge_off[l] + my_e;
-          int2 ed = m.edges[ge];
-          double2 n0 = m.nodes[no + ed.x], n1 = m.nodes[no + ed.y];
+          const int ge = m.edge_off[l] + my_e;
+          int2 ed = m.edges_g[ge];
+          double2 n0 = m.nodes[ed.x], n1 = m.nodes[ed.y];
           if (d_within_bounds(n0.x, n0.y, n1.x, n1.y, m.ori_fwd[ge], m.ori_rev[ge], s.x, s.y)) {
             dist_l = tc_fabs(d_distance_to_edge(n0.x, n0.y, n1.x, n1.y, s.x, s.y));
           } else {
@@ -340,25 +397,30 @@ __global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, in
   int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;  // [seg_cap][5]: layer, x0, y0, x1, y1
   if (tid < 6) cnt[tid] = 0;
   const int nn = m.total_nodes, ne = m.total_edges;
-  const int2* LE = m.edges_g;
-  for (int i = tid; i < nn; i += TC_NT) {  // camera.py:124-131
-    double2 n = m.nodes[i];
-    double h[4] = {n.x, n.y, 0.0, 1.0};
-    double p[3];
-    d_matmul<3, 4, 1>(pose, h, p);
-    Px[i] = p[0];
-    Py[i] = p[1];
-    Pz[i] = p[2];
-    flg[i] = p[2] < 0 ? 1 : 0;  // camera.py:70
+  for (int w = 0; w < nwin_n; w++) {  // camera.py:124-131
+    if (!single) cache_nodes(mc, m, w);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = (w * K + k) * TC_NT + tid;
+      if (i < nn) {
+        double h[4] = {mc.nd[k].x, mc.nd[k].y, 0.0, 1.0};
+        double p[3];
+        d_matmul<3, 4, 1>(pose, h, p);
+        Px[i] = p[0];
+        Py[i] = p[1];
+        Pz[i] = p[2];
+        flg[i] = p[2] < 0 ? 1 : 0;  // camera.py:70
+      }
+    }
   }
   __syncthreads();
-  cam_fixup_pass(Px, Py, Pz, flg, 1, LE, ne, true, -0.0000001, list, cnt + 0);   // camera.py:71-74
-  cam_fixup_pass(Px, Py, Pz, flg, 1, LE, ne, false, -0.0000001, list, cnt + 1);  // camera.py:75-77
+  cam_fixup_pass(mc, m, single, nwin_e, Px, Py, Pz, flg, 1, true, -0.0000001, list, cnt + 0);   // camera.py:71-74
+  cam_fixup_pass(mc, m, single, nwin_e, Px, Py, Pz, flg, 1, false, -0.0000001, list, cnt + 1);  // camera.py:75-77
   for (int i = tid; i < nn; i += TC_NT)
     if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
   __syncthreads();
-  cam_fixup_pass(Px, Py, Pz, flg, 2, LE, ne, true, -cam.max_range, list, cnt + 2);   // camera.py:81-83
-  cam_fixup_pass(Px, Py, Pz, flg, 2, LE, ne, false, -cam.max_range, list, cnt + 3);  // camera.py:84-86
+  cam_fixup_pass(mc, m, single, nwin_e, Px, Py, Pz, flg, 2, true, -cam.max_range, list, cnt + 2);   // camera.py:81-83
+  cam_fixup_pass(mc, m, single, nwin_e, Px, Py, Pz, flg, 2, false, -cam.max_range, list, cnt + 3);  // camera.py:84-86
   // Only nodes in front AND in range can be "visible" (camera.py:92-93): compact them so the two f64
   // divisions of the projection are paid for those nodes only.
   for (int i = tid; i < nn; i += TC_NT)
@@ -374,20 +436,29 @@ __global__ __launch_bounds__(TC_NT, TC_MIN_WAVES) void tc_env_kernel(KArgs a, in
     flg[i] |= vis ? (4 | 8) : 8;  // 8: slot Px[i] now holds the int32 pixel coordinates
   }
   __syncthreads();
-  for (int e = tid; e < ne; e += TC_NT) {  // camera.py:95
-    int2 ed = LE[e];
-    const int fa = flg[ed.x], fb = flg[ed.y];
-    if ((fa | fb) & 4) {
-      double u, v;
-      int2 pa = (fa & 8) ? ((int2*)Px)[ed.x] : cam_project(cam, Px[ed.x], Py[ed.x], Pz[ed.x], u, v);
-      int2 pb = (fb & 8) ? ((int2*)Px)[ed.y] : cam_project(cam, Px[ed.y], Py[ed.y], Pz[ed.y], u, v);
-      int k = atomicAdd(seg_cnt, 1);
-      int* o = segg + 5 * k;  // k < seg_cap == total edge count
-      o[0] = m.edge_layer[e];
-      o[1] = pa.x;
-      o[2] = pa.y;
-      o[3] = pb.x;
-      o[4] = pb.y;
+  for (int w = 0; w < nwin_e; w++) {  // camera.py:95
+    if (!single) cache_edges(mc, m, w);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int e = (w * K + k) * TC_NT + tid;
+      if (e < ne) {
+        const int2 ed = mc.ed[k];
+        const int fa = flg[ed.x], fb = flg[ed.y];
+        if ((fa | fb) & 4) {
+          double u, v;
+          int2 pa = (fa & 8) ? ((int2*)Px)[ed.x] : cam_project(cam, Px[ed.x], Py[ed.x], Pz[ed.x], u, v);
+          int2 pb = (fb & 8) ? ((int2*)Px)[ed.y] : cam_project(cam, Px[ed.y], Py[ed.y], Pz[ed.y], u, v);
+          int layer = 0;
+          for (int c = 1; c < m.C; c++) layer += e >= m.edge_off[c];
+          int j = atomicAdd(seg_cnt, 1);
+          int* o = segg + 5 * j;  // j < seg_cap == total edge count
+          o[0] = layer;
+          o[1] = pa.x;
+          o[2] = pa.y;
+          o[3] = pb.x;
+          o[4] = pb.y;
+        }
+      }
     }
   }
   __syncthreads();
@@ -762,6 +833,14 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
   if (!desc || !out) return TC_E_INVALID;
   *out = nullptr;
   const int C = desc->n_layers;
+  {
+    long long tn = 0;
+    for (int l = 0; l < C && l < TC_MAX_LAYERS; l++) tn += desc->node_count[l];
+    if (tn > 65535) {
+      set_err("tc_map_create: at most 65535 lane-line nodes (node ids are packed in 16 bits in the clip lists)");
+      return TC_E_INVALID;
+    }
+  }
   if (C < 1 || C > TC_MAX_LAYERS || desc->lanepath_node_count < 1 || desc->lanepath_edge_count < 0) {
     set_err("tc_map_create: need 1..16 lane-line layers and a non-empty lanepath");
     return TC_E_INVALID;
@@ -960,7 +1039,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   L.off_flg = off;
   off += align_up(m.total_nodes, 16);
   L.off_list = off;  // fix-up edge list / projection candidate list
-  off += align_up((m.total_edges > m.total_nodes ? m.total_edges : m.total_nodes) * 4, 16);
+  off += align_up((2 * m.total_edges > m.total_nodes ? 2 * m.total_edges : m.total_nodes) * 4, 16);
   L.off_cnt = off;
   off += 64;
   L.total = off;
@@ -980,7 +1059,9 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
     (void)hipFuncSetAttribute((const void*)tc_raster_kernel<false, TC_FMT_RGB>, hipFuncAttributeMaxDynamicSharedMemorySize, e->r_lds);
   }
   if (L.total > 48 * 1024) {
-    hipError_t he = hipFuncSetAttribute((const void*)tc_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    hipError_t he = hipFuncSetAttribute((const void*)tc_env_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void*)tc_env_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void*)tc_env_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (he != hipSuccess) {
       set_err(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he));
       delete e;
@@ -1140,8 +1221,12 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;
   const int slot = e->prof_n % TC_PROF_RING;
   if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], (hipStream_t)stream));
-  hipLaunchKernelGGL(tc_env_kernel, dim3(e->k.N), dim3(TC_NT), e->k.lds.total, (hipStream_t)stream, e->k, mode, cc,
-                     cdtype, man, spawn, mask, flags);
+  {
+    const int big = e->k.m.total_nodes > e->k.m.total_edges ? e->k.m.total_nodes : e->k.m.total_edges;
+    auto kern = big <= 5 * TC_NT ? tc_env_kernel<5> : big <= 8 * TC_NT ? tc_env_kernel<8> : tc_env_kernel<13>;
+    hipLaunchKernelGGL(kern, dim3(e->k.N), dim3(TC_NT), e->k.lds.total, (hipStream_t)stream, e->k, mode, cc, cdtype, man,
+                       spawn, mask, flags);
+  }
   HIP_TRY(hipGetLastError());
   if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], (hipStream_t)stream));
   if (!(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs) {
