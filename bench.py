@@ -150,12 +150,19 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
             sys.exit(2)
+    # rehearsal knobs for a one-GPU box: TC_BENCH_BACKEND=gloo TC_BENCH_ONE_GPU=1 lets several ranks share cuda:0
+    backend = os.environ.get("TC_BENCH_BACKEND", "nccl")
+    if os.environ.get("TC_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from tinycarlo_amd.vec_env import TinyCarloVecEnv
     from tinycarlo_amd.distributed import RankGather
@@ -205,7 +212,7 @@ def main():
         dt = float(t.item())
 
     gathered_ok = None
-    if dist is not None:  # functional check of the exchange step (outside the timed region)
+    if dist is not None and backend == "nccl":  # functional check of the exchange step (outside the timed region)
         g = gather if gather is not None else RankGather(env, what="flags")
         g.step()
         last = g.latest()

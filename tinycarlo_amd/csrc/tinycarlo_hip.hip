@@ -22,6 +22,7 @@
 #include "tc_device.h"
 
 #define TC_PROF_RING 64
+#define TC_MAX_SPLIT 8
 #define MODE_STEP 0
 #define MODE_RESET 1
 #define MODE_RENDER 2
@@ -52,6 +53,7 @@ struct KArgs {
   tc_buffers b;
   LdsLayout lds;
   int N;
+  int env0;    // first env of this launch (a step may be issued as several sub-batches)
   int* seg_g;  // [N][seg_cap][5] draw list of the current frame (library owned)
   int* seg_n;  // [N]
   int seg_cap;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) vo
                                                        const int* maneuver, const int* spawn_nodes,
                                                        const unsigned char* mask, unsigned int flags) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int env = blockIdx.x;
+  const int env = a.env0 + blockIdx.x;
   const int tid = threadIdx.x;
   if (env >= a.N) return;
   if (mode == MODE_RESET && mask && !mask[env]) return;  // whole workgroup leaves: no barrier below is reached
@@ -475,6 +477,7 @@ struct RCam {
 };
 struct RArgs {
   int N, C;
+  int env0;
   RCam cam;
   unsigned char colors[16][3];
   const int* seg_g;  // [N][seg_cap][5]
@@ -492,7 +495,7 @@ struct RArgs {
 template <bool THICK, int FMT>
 __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int env = blockIdx.x;
+  const int env = a.env0 + blockIdx.x;
   const int tid = threadIdx.x;
   if (env >= a.N) return;
   if (a.mask && !a.mask[env]) return;
@@ -804,6 +807,14 @@ struct tc_env {
   bool bound;
   int64_t obs_bytes;
   int r_off_tab, r_off_bits, r_lds;
+  // Optional (env var TC_SPLIT=n, default 1 = off): issue a step as n sub-batches of envs, sub-batch 0 on the
+  // caller's stream, the others on internal streams forked from / joined back into it with events, so the
+  // latency-bound simulate kernel of one sub-batch overlaps the issue-bound raster kernel of another.
+  // Measured on MI355X (cfg3): n=1 91.7 us, n=2 106.3 us, n=4 134.2 us -- the event fork/join costs more than
+  // the overlap gains, so it stays off.
+  int split;
+  hipStream_t side[TC_MAX_SPLIT];
+  hipEvent_t fork_ev, join_ev[TC_MAX_SPLIT];
   // optional per-kernel timing: a ring of (start, mid, end) HIP events recorded on the caller's stream
   int prof;    // 0 = off, n = record every n-th tc_step
   int prof_n;  // launches recorded so far
@@ -999,6 +1010,26 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   e->prof_n = 0;
   e->prof_calls = 0;
   memset(e->ev, 0, sizeof(e->ev));
+  e->split = 1;
+  if (const char* sp = getenv("TC_SPLIT")) {
+    int v = atoi(sp);
+    if (v >= 1 && v <= TC_MAX_SPLIT) e->split = v;
+  }
+  memset(e->side, 0, sizeof(e->side));
+  memset(e->join_ev, 0, sizeof(e->join_ev));
+  e->fork_ev = nullptr;
+  for (int p = 1; p < e->split; p++) {
+    if (hipStreamCreateWithFlags(&e->side[p], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->join_ev[p], hipEventDisableTiming) != hipSuccess) {
+      set_err("tc_env_create: cannot create internal streams");
+      delete e;
+      return TC_E_HIP;
+    }
+  }
+  if (e->split > 1 && hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming) != hipSuccess) {
+    delete e;
+    return TC_E_HIP;
+  }
   e->k.m = map->d;
   e->k.N = num_envs;
   DevCar& c = e->k.car;
@@ -1122,6 +1153,13 @@ extern "C" int tc_env_destroy(tc_env* e) {
   if (e && e->ev[0][0])
     for (int k = 0; k < 3; k++)
       for (int i = 0; i < TC_PROF_RING; i++) (void)hipEventDestroy(e->ev[k][i]);
+  if (e) {
+    for (int p = 1; p < TC_MAX_SPLIT; p++) {
+      if (e->side[p]) (void)hipStreamDestroy(e->side[p]);
+      if (e->join_ev[p]) (void)hipEventDestroy(e->join_ev[p]);
+    }
+    if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+  }
   if (e && e->k.seg_g) (void)hipFree(e->k.seg_g);
   if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
   delete e;
@@ -1162,11 +1200,13 @@ extern "C" int tc_env_set_camera(tc_env* e, const tc_camera_params* cam) {
 }
 
 static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
-                         void* stream) {
+                         void* stream, int env0 = 0, int count = -1) {
   {
     RArgs r;
     memset(&r, 0, sizeof(r));
     r.N = e->k.N;
+    r.env0 = env0;
+    if (count < 0) count = e->k.N;
     r.C = e->k.m.C;
     const DevCam& c = e->k.cam;
     r.cam.H = c.H; r.cam.W = c.W; r.cam.wpr = c.wpr; r.cam.band_rows = c.band_rows; r.cam.n_bands = c.n_bands;
@@ -1201,7 +1241,7 @@ static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_
     const bool thick = c.thickness > 1, cls = c.format == TC_FMT_CLASSES;
     auto kern = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
                       : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
-    hipLaunchKernelGGL(kern, dim3(e->k.N), dim3(TC_NT), e->r_lds, (hipStream_t)stream, r);
+    hipLaunchKernelGGL(kern, dim3(count), dim3(TC_NT), e->r_lds, (hipStream_t)stream, r);
     HIP_TRY(hipGetLastError());
   }
   return TC_OK;
@@ -1220,21 +1260,34 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   }
   const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;
   const int slot = e->prof_n % TC_PROF_RING;
-  if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], (hipStream_t)stream));
-  {
-    const int big = e->k.m.total_nodes > e->k.m.total_edges ? e->k.m.total_nodes : e->k.m.total_edges;
-    auto kern = big <= 5 * TC_NT ? tc_env_kernel<5> : big <= 8 * TC_NT ? tc_env_kernel<8> : tc_env_kernel<13>;
-    hipLaunchKernelGGL(kern, dim3(e->k.N), dim3(TC_NT), e->k.lds.total, (hipStream_t)stream, e->k, mode, cc, cdtype, man,
-                       spawn, mask, flags);
+  const int big = e->k.m.total_nodes > e->k.m.total_edges ? e->k.m.total_nodes : e->k.m.total_edges;
+  auto kern = big <= 5 * TC_NT ? tc_env_kernel<5> : big <= 8 * TC_NT ? tc_env_kernel<8> : tc_env_kernel<13>;
+  const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
+  const int N = e->k.N;
+  // sub-batches only pay off with an observation to rasterise and enough envs per part; profiled steps stay whole
+  int parts = (do_raster && !prof && N >= 256 * e->split) ? e->split : 1;
+  hipStream_t main = (hipStream_t)stream;
+  if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], main));
+  if (parts > 1) HIP_TRY(hipEventRecord(e->fork_ev, main));
+  for (int p = 0; p < parts; p++) {
+    const int env0 = (int)((long long)N * p / parts), env1 = (int)((long long)N * (p + 1) / parts);
+    hipStream_t st = p == 0 ? main : e->side[p];
+    if (p > 0) HIP_TRY(hipStreamWaitEvent(st, e->fork_ev, 0));
+    KArgs k = e->k;
+    k.env0 = env0;
+    hipLaunchKernelGGL(kern, dim3(env1 - env0), dim3(TC_NT), k.lds.total, st, k, mode, cc, cdtype, man, spawn, mask, flags);
+    HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
+    if (do_raster) {
+      int rc = launch_raster(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, mode == MODE_RESET ? mask : nullptr, flags, st, env0,
+                             env1 - env0);
+      if (rc != TC_OK) return rc;
+    }
+    if (p > 0) HIP_TRY(hipEventRecord(e->join_ev[p], st));
   }
-  HIP_TRY(hipGetLastError());
-  if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], (hipStream_t)stream));
-  if (!(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs) {
-    int rc = launch_raster(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, mode == MODE_RESET ? mask : nullptr, flags, stream);
-    if (rc != TC_OK) return rc;
-  }
+  for (int p = 1; p < parts; p++) HIP_TRY(hipStreamWaitEvent(main, e->join_ev[p], 0));
   if (prof) {
-    HIP_TRY(hipEventRecord(e->ev[2][slot], (hipStream_t)stream));
+    HIP_TRY(hipEventRecord(e->ev[2][slot], main));
     e->prof_n++;
   }
   return TC_OK;
