@@ -625,58 +625,6 @@ __device__ inline void r_line2_pixels(const Ras& r, int a, int b, int step, int 
   }
 }
 
-// Line2(): 16.16 fixed-point DDA (polygon outline)
-__device__ inline void r_line2(const Ras& r, long long p1x, long long p1y, long long p2x, long long p2y) {
-  if (!r_clip_line((long long)r.W << TC_XY_SHIFT, (long long)r.H << TC_XY_SHIFT, p1x, p1y, p2x, p2y)) return;
-  long long dx = p2x - p1x, dy = p2y - p1y;
-  long long j = dx < 0 ? -1 : 0;
-  long long ax = (dx ^ j) - j;
-  long long i = dy < 0 ? -1 : 0;
-  long long ay = (dy ^ i) - i;
-  long long x_step, y_step;
-  int ecount;
-  bool xmajor = ax > ay;
-  if (xmajor) {
-    dy = (dy ^ j) - j;
-    if (j) {
-      long long t = p1x; p1x = p2x; p2x = t;
-      t = p1y; p1y = p2y; p2y = t;
-    }
-    x_step = TC_XY_ONE;
-    y_step = d_sdiv(dy * TC_XY_ONE, ax | 1);
-    ecount = (int)((p2x - p1x) >> TC_XY_SHIFT);
-  } else {
-    dx = (dx ^ i) - i;
-    if (i) {
-      long long t = p1x; p1x = p2x; p2x = t;
-      t = p1y; p1y = p2y; p2y = t;
-    }
-    x_step = d_sdiv(dx * TC_XY_ONE, ay | 1);
-    y_step = TC_XY_ONE;
-    ecount = (int)((p2y - p1y) >> TC_XY_SHIFT);
-  }
-  p1x += (TC_XY_ONE >> 1);
-  p1y += (TC_XY_ONE >> 1);
-  r_put(r, (int)((p2x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), (int)((p2y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT));
-  if (xmajor) {
-    p1x >>= TC_XY_SHIFT;
-    while (ecount >= 0) {
-      r_put(r, (int)p1x, (int)(p1y >> TC_XY_SHIFT));
-      p1x++;
-      p1y += y_step;
-      ecount--;
-    }
-  } else {
-    p1y >>= TC_XY_SHIFT;
-    while (ecount >= 0) {
-      r_put(r, (int)(p1x >> TC_XY_SHIFT), (int)p1y);
-      p1x += x_step;
-      p1y++;
-      ecount--;
-    }
-  }
-}
-
 // The four polygon vertices travel as BY-VALUE scalars.  Any aggregate (array or struct behind a
 // reference) lets LLVM fold "select of loads" into "load of selected pointer", which pins the
 // aggregate in scratch memory -- and scratch write-back shows up as HBM traffic.
@@ -688,97 +636,7 @@ __device__ inline long long sel4(long long a0, long long a1, long long a2, long 
   return r;
 }
 
-// FillConvexPoly(v[4], shift = 16), LINE_8 -- the scanline part, restricted to rows [row_lo, row_hi).
-// Rows before the window are walked in closed form (OpenCV walks every row, also the negative ones, but
-// nothing except x += dx happens on a row that is not drawn), rows after it cannot matter.
-__device__ inline void r_fill_rows(const Ras& r, long long qx0, long long qx1, long long qx2, long long qx3,
-                                   long long qy0, long long qy1, long long qy2, long long qy3, int row_lo, int row_hi) {
-  const int npts = 4, shift = TC_XY_SHIFT;
-  const int delta = 1 << shift >> 1;
-  int e_idx[2], e_di[2], e_ye[2];
-  long long e_x[2], e_dx[2];
-  int imin = 0;
-  int edges = npts;
-  long long xmin, xmax, ymin, ymax;
-  xmin = xmax = qx0;
-  ymin = ymax = qy0;
-#pragma unroll
-  for (int i = 0; i < npts; i++) {
-    long long px = sel4(qx0, qx1, qx2, qx3, i), py = sel4(qy0, qy1, qy2, qy3, i);
-    if (py < ymin) {
-      ymin = py;
-      imin = i;
-    }
-    if (py > ymax) ymax = py;
-    if (px > xmax) xmax = px;
-    if (px < xmin) xmin = px;
-  }
-  xmin = (xmin + delta) >> shift;
-  xmax = (xmax + delta) >> shift;
-  ymin = (ymin + delta) >> shift;
-  ymax = (ymax + delta) >> shift;
-  if (d_wrap32(xmax) < 0 || d_wrap32(ymax) < 0 || d_wrap32(xmin) >= r.W || d_wrap32(ymin) >= r.H) return;
-  if (ymax > r.H - 1) ymax = r.H - 1;
-  int y = d_wrap32(ymin);
-  e_idx[0] = e_idx[1] = imin;
-  e_ye[0] = e_ye[1] = y;
-  e_di[0] = 1;
-  e_di[1] = npts - 1;
-  e_x[0] = e_x[1] = -TC_XY_ONE;
-  e_dx[0] = e_dx[1] = 0;
-  const int draw_lo = row_lo > 0 ? row_lo : 0;
-  const int last = (int)ymax < row_hi - 1 ? (int)ymax : row_hi - 1;
-  if (y > last) return;
-  do {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      if (y >= e_ye[i]) {
-        int idx0 = e_idx[i], di = e_di[i];
-        int idx = idx0 + di;
-        if (idx >= npts) idx -= npts;
-        for (; edges-- > 0;) {
-          int ty = d_wrap32((sel4(qy0, qy1, qy2, qy3, idx) + delta) >> shift);
-          if (ty > y) {
-            long long xs = sel4(qx0, qx1, qx2, qx3, idx0), xe = sel4(qx0, qx1, qx2, qx3, idx);
-            e_ye[i] = ty;
-            e_dx[i] = d_sdiv((xe - xs) * 2 + ((long long)ty - y), 2 * ((long long)ty - y));
-            e_x[i] = xs;
-            e_idx[i] = idx;
-            break;
-          }
-          idx0 = idx;
-          idx += di;
-          if (idx >= npts) idx -= npts;
-        }
-      }
-    }
-    if (edges < 0) break;
-    if (y >= draw_lo) {
-      long long xl = e_x[0], xr = e_x[1];
-      if (xl > xr) {
-        long long t = xl;
-        xl = xr;
-        xr = t;
-      }
-      int xx1 = d_wrap32((xl + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
-      int xx2 = d_wrap32((xr + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
-      if (xx2 >= 0 && xx1 < r.W) r_hline(r, y, xx1, xx2);
-      e_x[0] += e_dx[0];
-      e_x[1] += e_dx[1];
-    } else {
-      long long nxt = draw_lo;
-      if (e_ye[0] < nxt) nxt = e_ye[0];
-      if (e_ye[1] < nxt) nxt = e_ye[1];
-      if (ymax + 1 < nxt) nxt = ymax + 1;
-      long long k = nxt - y;
-      if (k < 1) k = 1;
-      e_x[0] += e_dx[0] * k;
-      e_x[1] += e_dx[1] * k;
-      y += (int)(k - 1);
-    }
-  } while (++y <= last);
-}
-
+// FillConvexPoly(v[4], shift = 16, LINE_8) = 4 outline edges (Line2, above) + the scanline fill below.
 // FillConvexPoly's two edge walkers as closed-form pieces.  The scanline loop of drawing.cpp is a
 // sequence of "events" (a walker reaches the end row of its polygon edge and picks the next one, with a
 // shared budget of npts edges) between which both walkers just add dx per row.  This runs the event
@@ -898,38 +756,6 @@ __device__ inline void r_fill_row(const Ras& r, int row, int np, int wmask, cons
   r_hline(r, ok ? row : -1, xx1, xx2);
 }
 
-// rows of the image a FillConvexPoly of this quad can touch: [lo, hi], empty when lo > hi
-__device__ inline void r_fill_row_range(int W, int H, long long qx0, long long qx1, long long qx2, long long qx3,
-                                        long long qy0, long long qy1, long long qy2, long long qy3, int& lo, int& hi) {
-  const int delta = TC_XY_ONE >> 1;
-  long long xmin = qx0, xmax = qx0, ymin = qy0, ymax = qy0;
-  xmin = qx1 < xmin ? qx1 : xmin; xmin = qx2 < xmin ? qx2 : xmin; xmin = qx3 < xmin ? qx3 : xmin;
-  xmax = qx1 > xmax ? qx1 : xmax; xmax = qx2 > xmax ? qx2 : xmax; xmax = qx3 > xmax ? qx3 : xmax;
-  ymin = qy1 < ymin ? qy1 : ymin; ymin = qy2 < ymin ? qy2 : ymin; ymin = qy3 < ymin ? qy3 : ymin;
-  ymax = qy1 > ymax ? qy1 : ymax; ymax = qy2 > ymax ? qy2 : ymax; ymax = qy3 > ymax ? qy3 : ymax;
-  xmin = (xmin + delta) >> TC_XY_SHIFT;
-  xmax = (xmax + delta) >> TC_XY_SHIFT;
-  ymin = (ymin + delta) >> TC_XY_SHIFT;
-  ymax = (ymax + delta) >> TC_XY_SHIFT;
-  lo = 0;
-  hi = -1;
-  if (d_wrap32(xmax) < 0 || d_wrap32(ymax) < 0 || d_wrap32(xmin) >= W || d_wrap32(ymin) >= H) return;
-  if (ymax > H - 1) ymax = H - 1;
-  int y = d_wrap32(ymin);
-  lo = y > 0 ? y : 0;
-  hi = (int)ymax;
-}
-
-// FillConvexPoly = outline (4 x Line2) + scanline fill
-__device__ inline void r_fill_convex_poly4(const Ras& r, long long qx0, long long qx1, long long qx2, long long qx3,
-                                           long long qy0, long long qy1, long long qy2, long long qy3) {
-  r_line2(r, qx3, qy3, qx0, qy0);
-  r_line2(r, qx0, qy0, qx1, qy1);
-  r_line2(r, qx1, qy1, qx2, qy2);
-  r_line2(r, qx2, qy2, qx3, qy3);
-  r_fill_rows(r, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, r.y0, r.y1);
-}
-
 // Circle(center, radius, fill)
 __device__ inline void r_circle_fill(const Ras& r, int cx, int cy, int radius) {
   int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
@@ -982,30 +808,6 @@ __device__ inline bool r_quad(int x0, int y0, int x1, int y1, int thickness, lon
   qx0 = p0x + dpx; qx1 = p0x - dpx; qx2 = p1x - dpx; qx3 = p1x + dpx;
   qy0 = p0y + dpy; qy1 = p0y - dpy; qy2 = p1y - dpy; qy3 = p1y + dpy;
   return true;
-}
-
-// PolyLine(open, 2 points) -> ThickLine(p0, p1, thickness, LINE_8, flags = 3, shift = 0)
-__device__ inline void r_thick_line(const Ras& r, int x0, int y0, int x1, int y1, int thickness) {
-  long long p0x = (long long)x0 * TC_XY_ONE, p0y = (long long)y0 * TC_XY_ONE;
-  long long p1x = (long long)x1 * TC_XY_ONE, p1y = (long long)y1 * TC_XY_ONE;
-  if (thickness <= 1) {
-    r_line_bresenham(r, (p0x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT, (p0y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT,
-                     (p1x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT, (p1y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
-    return;
-  }
-  const double INV_XY_ONE = 1. / TC_XY_ONE;
-  double dx = (double)(p0x - p1x) * INV_XY_ONE, dy = (double)(p1y - p0y) * INV_XY_ONE;
-  double rr = dx * dx + dy * dy;
-  int odd = thickness & 1;
-  long long th = (long long)thickness << (TC_XY_SHIFT - 1);
-  if (tc_fabs(rr) > 2.2204460492503131e-16) {
-    rr = ((double)th + odd * TC_XY_ONE * 0.5) / sqrt(rr);
-    long long dpx = __double2int_rn(dy * rr), dpy = __double2int_rn(dx * rr);
-    r_fill_convex_poly4(r, p0x + dpx, p0x - dpx, p1x - dpx, p1x + dpx, p0y + dpy, p0y - dpy, p1y - dpy, p1y + dpy);
-  }
-  int rad = (int)((th + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
-  r_circle_fill(r, d_wrap32((p0x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), d_wrap32((p0y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), rad);
-  r_circle_fill(r, d_wrap32((p1x + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), d_wrap32((p1y + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT), rad);
 }
 
 #endif  // TC_DEVICE_H

@@ -1,14 +1,15 @@
 // tinycarlo_hip.hip -- libtinycarlo_hip.so: kernels + C ABI (include/tinycarlo_hip.h).
 //
-// Build (see build.py): hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared
+// Build (csrc/Makefile): hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared
 //
-// Kernel layout: one 64-lane wavefront (= one workgroup) per env, N workgroups per launch.
-//   phase A  kinematics + lanepath tracking + CTE/heading   (car.py:70-148, 46-53)   wave-uniform scalar math
-//   phase B  nearest lane-line edge per layer + distance    (layer.py:33-44, car.py:55-64)
-//            node distances staged in LDS once, edges strided over lanes, shuffle argmin
-//   phase C  camera: transform -> 4 clip passes -> project -> visibility -> draw list   (camera.py:52-110)
-//            rasterise cv2.polylines into LDS bit-planes, expand to uint8 and store with
-//            16-byte-per-lane coalesced stores (zeros included: the frame is written exactly once)
+// One tc_step = two launches, one 64-lane wavefront (= one workgroup) per env in both:
+//   tc_env_kernel<K>      phase A  kinematics + lanepath tracking + CTE/heading   (car.py:70-148, 46-53)
+//                         phase B  nearest lane-line edge per layer + distance    (layer.py:33-44, car.py:55-64)
+//                         phase C  camera: transform -> 4 clip passes -> project -> visibility -> draw list
+//                                  (camera.py:52-110), handed over through a small global buffer
+//   tc_raster_kernel<..>  cv2.polylines of the draw list into LDS bit-planes (renderer.py:36-51), expanded to
+//                         uint8 and stored with 16-byte-per-lane coalesced stores (zeros included: a class-mask
+//                         frame is written exactly once)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -38,11 +39,9 @@
 
 #define RB 32        // segments rasterised per batch
 #define LCH 8        // outline steps per chunk
-#define FCH 8        // fill rows per chunk
 
 struct LdsLayout {
-  int off_p, off_flg, off_list, off_seg, off_bits, off_cnt;
-  int seg_cap;
+  int off_p, off_flg, off_list, off_cnt;
   int total;
 };
 
@@ -659,8 +658,7 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
     __syncthreads();
     if (a.flags & DBG_SKIP_STORE) {
     } else if (FMT == TC_FMT_CLASSES) {
-      if (false) {
-      } else if ((W & 15) == 0) {
+      if ((W & 15) == 0) {
         // 16 pixels -> one 16-byte store per lane, consecutive lanes on consecutive addresses
         // (two 16-byte stores per lane at a 32-byte lane stride were tried: 2x slower, half-line writes)
         const int g = W >> 4;  // 16-pixel groups per row
