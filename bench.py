@@ -262,7 +262,7 @@ def main():
                                        "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)" if traffic else None},
     }
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(w, cfg, args.cpu_budget)
         print(json.dumps(out), flush=True)
     if dist is not None:
