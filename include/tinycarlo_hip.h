@@ -144,6 +144,11 @@ int tc_env_destroy(tc_env* env);
 int tc_env_bind(tc_env* env, const tc_buffers* buffers);
 /* New E/K (and range / thickness) for all envs; takes effect for launches enqueued afterwards. */
 int tc_env_set_camera(tc_env* env, const tc_camera_params* cam);
+/* Per-env cameras (domain randomisation: examples/train_stanley_il.py:53-57 changes camera.orientation / fov and
+ * calls update_params() once per episode; batched, that is one E and K per env).  E: device double [N][12],
+ * K: device double [N][9], caller owned and read by every launch until replaced; (NULL, NULL) returns to the shared
+ * camera of tc_env_create / tc_env_set_camera.  Resolution, max_range, thickness and format stay shared. */
+int tc_env_set_camera_per_env(tc_env* env, const double* E, const double* K);
 /* bytes of one env's observation */
 int64_t tc_env_obs_bytes(const tc_env* env);
 /* dynamic LDS bytes one workgroup of the step kernel uses (for occupancy reporting) */

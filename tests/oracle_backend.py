@@ -84,6 +84,7 @@ class OracleVecEnv(TinyCarloVecEnv):
             self._o.obs[~mk] = keep_obs[~mk]
         no_obs = bool(self._oflags() & orc.F_NO_OBSERVATION)
         self._pull(with_obs=not no_obs)
+        self._rerender_env_cams()
         self._keep = (torch.as_tensor(np.asarray(spawn_nodes, dtype=np.int32)), mask)
         self._was_reset = True
 
@@ -94,6 +95,7 @@ class OracleVecEnv(TinyCarloVecEnv):
         no_obs = bool(self._oflags() & orc.F_NO_OBSERVATION)
         self._o.step(car_control.double().numpy(), maneuver.numpy(), flags=self._oflags(), with_obs=not no_obs)
         self._pull(with_obs=not no_obs)
+        self._rerender_env_cams()
 
     def render_current(self):
         self._push()
@@ -106,6 +108,26 @@ class OracleVecEnv(TinyCarloVecEnv):
 
     def _push_camera(self, cam):
         self._o.set_camera(cam)
+
+    def _push_env_cameras(self, E, K):
+        self._env_cams = None if E is None else (np.array(E, dtype=np.float64), np.array(K, dtype=np.float64))
+
+    def _rerender_env_cams(self):
+        """per-env cameras: the batch oracle has one camera, so frames are redone env by env with E/K swapped in"""
+        if getattr(self, "_env_cams", None) is None or (self._oflags() & orc.F_NO_OBSERVATION):
+            return
+        import ctypes as C
+        E, K = self._env_cams
+        keepE, keepK = list(self._o.cam.E), list(self._o.cam.K)
+        for i in range(self.num_envs):
+            self._o.cam.E[:] = list(E[i])
+            self._o.cam.K[:] = list(K[i])
+            seg, _ = self._o.segments(i)
+            orc.lib().orc_render(self._o.map.h, C.byref(self._o.cam), orc._ip(np.ascontiguousarray(seg)) if len(seg) else None,
+                                 len(seg), orc._bp(self._o.obs[i]))
+        self._o.cam.E[:] = keepE
+        self._o.cam.K[:] = keepK
+        self.out["obs"].copy_(torch.from_numpy(self._o.obs.reshape((self.num_envs,) + self._obs_shape).copy()))
 
     def close(self):
         pass

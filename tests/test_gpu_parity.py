@@ -248,3 +248,45 @@ def test_camera_update_params():
     env.step({"car_control": cc, "maneuver": man})
     assert_same(env, o, env.n_classes)
     env.close()
+
+
+def test_per_env_cameras():
+    """tc_env_set_camera_per_env: three camera variants spread over the batch, frames checked against one oracle
+    per variant (state and info do not depend on the camera)."""
+    N = 24
+    env = make_env("simple_layout", "r64", "classes", N)
+    oris = [[22, 0, 0], [31, 2, -5], [12, -3, 7]]
+    fovs = [80, 96, 68]
+    pick = np.arange(N) % 3
+    env.set_env_cameras(orientation=[oris[k] for k in pick], fov=[fovs[k] for k in pick])
+    from tinycarlo_amd.camera import Camera
+    from common import load_cfg
+    oracles = []
+    for k in range(3):
+        cc = copy.deepcopy(env.config["camera"])
+        cc.update(orientation=oris[k], fov=fovs[k])
+        o = orc.Oracle(env.map, env.car_params, Camera(cc), orc.FMT_CLASSES, N, threads=4)
+        oracles.append(o)
+    env.reset(seed=21)
+    nodes = env._keep[0].cpu().numpy()
+    for o in oracles:
+        o.reset(nodes)
+    rng = np.random.default_rng(3)
+    for t in range(12):
+        cc = np.stack([rng.uniform(0.3, 1, N), rng.uniform(-1, 1, N)], axis=1)
+        man = rng.integers(0, 4, N).astype(np.int32)
+        env.step({"car_control": cc, "maneuver": man})
+        for o in oracles:
+            o.step(cc, man)
+        assert_same(env, oracles[0], env.n_classes, check_obs=False, label=f"per-env cams step {t}")
+        got = env.out["obs"].cpu().numpy().reshape(N, -1)
+        for i in range(N):
+            assert np.array_equal(got[i], oracles[pick[i]].obs[i]), (t, i)
+    assert not np.array_equal(oracles[0].obs, oracles[1].obs)
+    env.set_env_cameras()  # shared camera again
+    cc = np.tile([[0.5, 0.0]], (N, 1))
+    man = np.zeros(N, dtype=np.int32)
+    env.step({"car_control": cc, "maneuver": man})
+    oracles[0].step(cc, man)
+    assert_same(env, oracles[0], env.n_classes, label="shared again")
+    env.close()

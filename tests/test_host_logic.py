@@ -158,6 +158,32 @@ def test_camera_update_params_changes_frame():
     assert obs0.shape == obs1.shape and (obs0 != obs1).any()
 
 
+def test_per_env_cameras_match_single_camera_envs():
+    """set_env_cameras: env i with (orientation_i, fov_i) renders what a single env with that camera renders."""
+    from tinycarlo_amd.camera import Camera
+    cfg = cfg_for("simple_layout", "r64")
+    vec = OracleVecEnv(cfg, num_envs=3)
+    oris = [[22, 0, 0], [30, 3, -4], [15, -2, 6]]
+    fovs = [80, 95, 70]
+    vec.set_env_cameras(orientation=oris, fov=fovs)
+    E, K = vec._env_cams
+    for i in range(3):
+        c = copy.deepcopy(cfg["camera"])
+        c.update(orientation=oris[i], fov=fovs[i])
+        cam = Camera(c)
+        assert np.array_equal(E[i], cam.E.reshape(-1)) and np.array_equal(K[i], cam.K.reshape(-1))
+    obs, _ = vec.reset(seed=11)
+    for i in range(3):
+        c = copy.deepcopy(cfg)
+        c["camera"].update(orientation=oris[i], fov=fovs[i])
+        single = TinyCarloEnv(config=c)
+        o1, _ = single.reset(seed=11 + i)
+        assert np.array_equal(o1, obs[i].numpy()), i
+    assert not torch.equal(obs[1], obs[0])
+    vec.set_env_cameras()  # back to the shared camera
+    assert vec._env_cams is None
+
+
 # ------------------------------------------------------------------ wrappers (wrapper/*.py of the reference)
 def test_reward_helpers_scalar_and_tensor():
     assert linear_reward(0.0, 0.1) == 1.0 and linear_reward(0.05, 0.1) == pytest.approx(0.5) and linear_reward(0.2, 0.1) == 0.0

@@ -53,6 +53,8 @@ struct KArgs {
   LdsLayout lds;
   int N;
   int env0;    // first env of this launch (a step may be issued as several sub-batches)
+  const double* cam_E;  // optional per-env extrinsics [N][12] (NULL: cam.E for every env)
+  const double* cam_K;  // optional per-env intrinsics [N][9]
   int* seg_g;  // [N][seg_cap][5] draw list of the current frame (library owned)
   int* seg_n;  // [N]
   int seg_cap;
@@ -171,10 +173,10 @@ __device__ inline unsigned int spread4(unsigned int x) {  // x < 16: 4 bits -> 4
 }
 
 // camera.py:133-142 for one node + the np.int32 cast of renderer.py:43,50
-__device__ inline int2 cam_project(const DevCam& cam, double X, double Y, double Z, double& u, double& v) {
+__device__ inline int2 cam_project(const double* K, double X, double Y, double Z, double& u, double& v) {
   double P3[3] = {X, Y, Z};
   double h[3];
-  d_matmul<3, 3, 1>(cam.K, P3, h);
+  d_matmul<3, 3, 1>(K, P3, h);
   u = h[0] / h[2];
   v = h[1] / h[2];
   return make_int2(d_np_int32(u), d_np_int32(v));
@@ -381,14 +383,19 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) vo
   if ((flags & TC_F_NO_OBSERVATION) || b.obs == nullptr) return;
   if (flags & DBG_SKIP_CAMERA) return;
   const DevCam& cam = a.cam;
-  double pose[12];
+  double pose[12], Kc[9];
   {
+    double Ec[12];  // this env's camera (camera.py:23-24,48-50): shared, or its own after tc_env_set_camera_per_env
+#pragma unroll
+    for (int i = 0; i < 12; i++) Ec[i] = a.cam_E ? a.cam_E[(size_t)env * 12 + i] : cam.E[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Kc[i] = a.cam_K ? a.cam_K[(size_t)env * 9 + i] : cam.K[i];
     double cth = tc_cos(-s.theta), sth = tc_sin(-s.theta);  // car.py:159-165
     double R[16] = {cth, -sth, 0, 0, sth, cth, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     double Tm[16] = {1, 0, 0, -s.x, 0, 1, 0, -s.y, 0, 0, 1, 0, 0, 0, 0, 1};
     double car3d[16];
     d_matmul<4, 4, 4>(R, Tm, car3d);
-    d_matmul<3, 4, 4>(cam.E, car3d, pose);  // camera.py:62
+    d_matmul<3, 4, 4>(Ec, car3d, pose);  // camera.py:62
   }
   // All lane-line layers are processed together: node ids are made global (edges_g), so each of the
   // passes below is ONE loop over all nodes / edges instead of one per layer (the layers never share
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) vo
   for (int k = tid; k < ncand; k += TC_NT) {  // camera.py:133-142, 90
     const int i = list[k];
     double u, v;
-    int2 q = cam_project(cam, Px[i], Py[i], Pz[i], u, v);
+    int2 q = cam_project(Kc, Px[i], Py[i], Pz[i], u, v);
     bool vis = (u > 0) && (u < cam.W) && (v > 0) && (v < cam.H);
     ((int2*)Px)[i] = q;  // renderer.py:43,50 np.int32(...)
     flg[i] |= vis ? (4 | 8) : 8;  // 8: slot Px[i] now holds the int32 pixel coordinates
@@ -447,8 +454,8 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) vo
         const int fa = flg[ed.x], fb = flg[ed.y];
         if ((fa | fb) & 4) {
           double u, v;
-          int2 pa = (fa & 8) ? ((int2*)Px)[ed.x] : cam_project(cam, Px[ed.x], Py[ed.x], Pz[ed.x], u, v);
-          int2 pb = (fb & 8) ? ((int2*)Px)[ed.y] : cam_project(cam, Px[ed.y], Py[ed.y], Pz[ed.y], u, v);
+          int2 pa = (fa & 8) ? ((int2*)Px)[ed.x] : cam_project(Kc, Px[ed.x], Py[ed.x], Pz[ed.x], u, v);
+          int2 pb = (fb & 8) ? ((int2*)Px)[ed.y] : cam_project(Kc, Px[ed.y], Py[ed.y], Pz[ed.y], u, v);
           int layer = 0;
           for (int c = 1; c < m.C; c++) layer += e >= m.edge_off[c];
           int j = atomicAdd(seg_cnt, 1);
@@ -1181,6 +1188,13 @@ extern "C" int tc_env_bind(tc_env* e, const tc_buffers* b) {
   }
   e->k.b = *b;
   e->bound = true;
+  return TC_OK;
+}
+
+extern "C" int tc_env_set_camera_per_env(tc_env* e, const double* E, const double* K) {
+  if (!e || ((E == nullptr) != (K == nullptr))) return TC_E_INVALID;
+  e->k.cam_E = E;
+  e->k.cam_K = K;
   return TC_OK;
 }
 

@@ -162,6 +162,42 @@ class TinyCarloVecEnv(gym.Env):
         cp = nat.make_camera_params(cam, self._fmt)
         nat.check(nat.lib().tc_env_set_camera(self._h, C.byref(cp)), "tc_env_set_camera")
 
+    def set_env_cameras(self, orientation=None, fov=None, position=None) -> None:
+        """Per-env camera extrinsics / intrinsics (domain randomisation, train_stanley_il.py:53-57).
+
+        orientation: [N,3] degrees (pitch, roll, yaw), fov: [N] degrees, position: [N,3] metres; any of them may
+        be None (keep the shared camera's value).  ``set_env_cameras()`` with no argument returns to the single
+        shared camera.  E and K are computed per env on the host with the same code as ``Camera.update_params``."""
+        if orientation is None and fov is None and position is None:
+            self._push_env_cameras(None, None)
+            return
+        N = self.num_envs
+        ori = np.broadcast_to(np.asarray(self.camera.orientation if orientation is None else orientation, dtype=np.float64), (N, 3))
+        fv = np.broadcast_to(np.asarray(self.camera.fov if fov is None else fov, dtype=np.float64), (N,))
+        pos = np.broadcast_to(np.asarray(self.camera.position if position is None else position, dtype=np.float64), (N, 3))
+        E = np.empty((N, 12), dtype=np.float64)
+        K = np.empty((N, 9), dtype=np.float64)
+        cache: Dict[Any, Any] = {}
+        cfg = dict(self.config["camera"])
+        for i in range(N):
+            key = (tuple(ori[i]), float(fv[i]), tuple(pos[i]))
+            if key not in cache:
+                cfg.update(orientation=list(ori[i]), fov=float(fv[i]), position=list(pos[i]))
+                c = Camera(cfg)
+                cache[key] = (c.E.reshape(-1), c.K.reshape(-1))
+            E[i], K[i] = cache[key]
+        self._push_env_cameras(E, K)
+
+    def _push_env_cameras(self, E, K) -> None:
+        if E is None:
+            self._env_cams = None
+            nat.check(nat.lib().tc_env_set_camera_per_env(self._h, None, None), "tc_env_set_camera_per_env")
+            return
+        Et = torch.as_tensor(E, dtype=torch.float64).to(self.device).contiguous()
+        Kt = torch.as_tensor(K, dtype=torch.float64).to(self.device).contiguous()
+        self._env_cams = (Et, Kt)  # keep the device copies alive: the library reads them on every launch
+        nat.check(nat.lib().tc_env_set_camera_per_env(self._h, Et.data_ptr(), Kt.data_ptr()), "tc_env_set_camera_per_env")
+
     def _to_dev(self, key: str, a, dtype: torch.dtype, shape: Tuple[int, ...]) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
             t = a
