@@ -290,3 +290,87 @@ def test_per_env_cameras():
     oracles[0].step(cc, man)
     assert_same(env, oracles[0], env.n_classes, label="shared again")
     env.close()
+
+
+def test_step_captures_into_a_hip_graph():
+    """tc_step only enqueues work on the caller's stream (no allocation, no synchronisation), so a step can be
+    captured once with torch.cuda.graph and replayed: replays must equal eager steps bit for bit."""
+    N = 256
+    env_g = make_env("simple_layout", "r64", "classes", N)
+    env_e = make_env("simple_layout", "r64", "classes", N)
+    env_g.reset(seed=5)
+    env_e.reset(seed=5)
+    rng = np.random.default_rng(8)
+    cc_static = torch.zeros((N, 2), dtype=torch.float32, device="cuda:0")
+    mn_static = torch.zeros(N, dtype=torch.int32, device="cuda:0")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):  # warm-up on the capture stream, as torch recommends
+        env_g.step_device(cc_static, mn_static)
+    torch.cuda.current_stream().wait_stream(s)
+    env_e.step_device(cc_static, mn_static)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        env_g.step_device(cc_static, mn_static)
+    env_e.step_device(cc_static, mn_static)   # the captured step has not run yet: replay it once to stay aligned
+    g.replay()
+    for t in range(6):
+        cc = torch.from_numpy(np.stack([rng.uniform(0.3, 1, N), rng.uniform(-1, 1, N)], axis=1).astype(np.float32)).cuda()
+        mn = torch.from_numpy(rng.integers(0, 4, N).astype(np.int32)).cuda()
+        cc_static.copy_(cc)
+        mn_static.copy_(mn)
+        g.replay()
+        env_e.step_device(cc, mn)
+    torch.cuda.synchronize()
+    for k in env_e.state:
+        assert torch.equal(env_g.state[k], env_e.state[k]), k
+    for k in ("cte", "reward", "laneline_distances", "nearest_edge", "obs", "terminated", "truncated"):
+        assert torch.equal(env_g.out[k], env_e.out[k]), k
+    assert int(env_g.out["obs"].max()) == 255
+    env_g.close()
+    env_e.close()
+
+
+def test_large_synthetic_map_multi_window(tmp_path):
+    """A map beyond the single-window register cache (13*64 nodes / edges) and beyond 48 KB of LDS: knuffingen's
+    lane-line layers three times over (15 layers, 2481 nodes, 2217 edges).  Exercises the window loop of
+    tc_env_kernel<13>, C = 15 class planes and the dynamic-LDS attribute path."""
+    import json
+    import os
+    from tinycarlo_amd.config import bundled_config
+    from tinycarlo_amd.vec_env import TinyCarloVecEnv
+    cfg, path = load_cfg("knuffingen")
+    cfg = copy.deepcopy(cfg)
+    src = os.path.join(os.path.dirname(path), cfg["map"]["json_path"])
+    with open(src) as f:
+        mj = json.load(f)
+    big = {}
+    for rep in range(3):
+        for name, layer in mj["lanelines"].items():
+            shift = 37 * rep  # px: copies are offset so that they do not coincide
+            big[f"{name}_{rep}"] = {"layer_color": [(c + 40 * rep) % 256 for c in layer["layer_color"]],
+                                    "nodes": [[n[0] + shift, n[1] - shift] for n in layer["nodes"]],
+                                    "edges": layer["edges"]}
+    mj["lanelines"] = big
+    mp = tmp_path / "big.json"
+    mp.write_text(json.dumps(mj))
+    cfg["map"]["json_path"] = str(mp)
+    cfg["camera"]["resolution"] = [64, 64]
+    for fmt in ("classes", "rgb"):
+        cfg["sim"]["observation_space_format"] = fmt
+        N = 48
+        env = TinyCarloVecEnv(cfg, num_envs=N, device="cuda:0", autoreset=True, spawn_queue_len=4)
+        assert env.n_classes == 15 and env.lds_bytes > 48 * 1024
+        o = make_oracle(env)
+        env.reset(seed=77)
+        o.spawn_queue = env._aux["spawn_queue"].cpu().numpy()
+        o.reset(env._keep[0].cpu().numpy())
+        assert_same(env, o, env.n_classes, label="big reset")
+        rng = np.random.default_rng(1)
+        for t in range(10):
+            cc = np.stack([rng.uniform(0.3, 1, N), rng.uniform(-1, 1, N)], axis=1)
+            man = rng.integers(0, 4, N).astype(np.int32)
+            o.step(cc, man, flags=orc.F_AUTORESET)
+            env.step({"car_control": cc, "maneuver": man})
+            assert_same(env, o, env.n_classes, label=f"big map {fmt} step {t}")
+        assert int(env.out["obs"].max()) > 0
+        env.close()
