@@ -225,11 +225,12 @@ def main():
     bytes_per_env_step = B_STATE + b_obs
     step_s = ev_ms / 1e3 / K  # HIP events on the launch stream around the K timed steps (both kernels)
     prof = env.profile_read()  # per-kernel HIP events sampled over the timed region
-    # One step = two back-to-back kernels of similar length (simulate: state/action/info, 240 B per env;
-    # raster: the observation, written once).  The roofline unit is therefore the step: SURVEY 8d's
-    # algorithmic bytes per env-step x envs per launch, divided by the summed kernel durations.
-    kname = "tc_env_kernel+tc_raster_kernel" if b_obs else "tc_env_kernel"
-    kernel_s = (prof["simulate_us"] + (prof["raster_us"] if b_obs else 0.0)) * 1e-6
+    # One step = one fused kernel (tc_step_kernel: simulate + raster by the same wavefront), or, for large maps /
+    # TC_FUSE=0, two back-to-back kernels.  Either way the roofline unit is the step: SURVEY 8d's algorithmic
+    # bytes per env-step x envs per launch, divided by the (summed) kernel duration.
+    fused = bool(b_obs) and prof["raster_us"] < 0.25 * prof["simulate_us"]  # one tc_step_kernel launch per step
+    kname = "tc_step_kernel" if fused else ("tc_env_kernel+tc_raster_kernel" if b_obs else "tc_env_kernel")
+    kernel_s = (prof["simulate_us"] + (prof["raster_us"] if b_obs and not fused else 0.0)) * 1e-6
     kbytes = bytes_per_env_step * n
     achieved = kbytes / kernel_s / 1e9
     traffic = pmc_traffic(args.workload, kname) if n == WORKLOADS[args.workload]["envs"] else None
@@ -254,7 +255,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": kname, "kernel_us": kernel_s * 1e6, "algorithmic_bytes_per_launch": kbytes,
-                     "kernels_us": {"tc_env_kernel": prof["simulate_us"], "tc_raster_kernel": prof["raster_us"]},
+                     "kernels_us": ({"tc_step_kernel": prof["simulate_us"]} if fused else
+                                    {"tc_env_kernel": prof["simulate_us"], "tc_raster_kernel": prof["raster_us"]}),
                      "event_samples": prof["launches"],
                      "step_us": step_s * 1e6, "step_algorithmic_bytes": bytes_per_env_step * n,
                      "step_achieved_GBs": bytes_per_env_step * n / step_s / 1e9,

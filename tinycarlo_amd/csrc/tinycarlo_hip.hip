@@ -195,15 +195,13 @@ __device__ inline int wave_incl_scan(int v) {
 #ifndef TC_MIN_WAVES
 #define TC_MIN_WAVES 4
 #endif
+// Stage 1 (simulate) for one env by one wavefront.  Returns false when nothing is to be rasterised for this env.
 template <int K>
-__global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) void tc_env_kernel(KArgs a, int mode, const void* car_control, int cdtype,
-                                                       const int* maneuver, const int* spawn_nodes,
-                                                       const unsigned char* mask, unsigned int flags) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int env = a.env0 + blockIdx.x;
+__device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, int mode, const void* car_control, int cdtype,
+                                const int* maneuver, const int* spawn_nodes, const unsigned char* mask,
+                                unsigned int flags) {
   const int tid = threadIdx.x;
-  if (env >= a.N) return;
-  if (mode == MODE_RESET && mask && !mask[env]) return;  // whole workgroup leaves: no barrier below is reached
+  if (mode == MODE_RESET && mask && !mask[env]) return false;  // whole workgroup skips: no barrier below is reached
 
   const DevMap& m = a.m;
   const tc_buffers& b = a.b;
@@ -380,8 +378,8 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) vo
   }
 
   // ---- phase C: camera (camera.py:52-110) + raster (renderer.py:36-51)
-  if ((flags & TC_F_NO_OBSERVATION) || b.obs == nullptr) return;
-  if (flags & DBG_SKIP_CAMERA) return;
+  if ((flags & TC_F_NO_OBSERVATION) || b.obs == nullptr) return false;
+  if (flags & DBG_SKIP_CAMERA) return false;
   const DevCam& cam = a.cam;
   double pose[12], Kc[9];
   {
@@ -470,7 +468,18 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) vo
     }
   }
   __syncthreads();
-  if (tid == 0) a.seg_n[env] = *seg_cnt;  // handed to tc_raster_kernel through global memory
+  if (tid == 0) a.seg_n[env] = *seg_cnt;  // handed to the raster stage through global memory
+  return true;
+}
+
+template <int K>
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) void tc_env_kernel(KArgs a, int mode, const void* car_control, int cdtype,
+                                                       const int* maneuver, const int* spawn_nodes,
+                                                       const unsigned char* mask, unsigned int flags) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int env = a.env0 + blockIdx.x;
+  if (env >= a.N) return;
+  sim_body<K>(a, smem, env, mode, car_control, cdtype, maneuver, spawn_nodes, mask, flags);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -499,12 +508,8 @@ struct RArgs {
 #define TC_RASTER_WAVES 4
 #endif
 template <bool THICK, int FMT>
-__global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int env = a.env0 + blockIdx.x;
+__device__ inline void raster_body(const RArgs& a, unsigned char* smem, int env) {
   const int tid = threadIdx.x;
-  if (env >= a.N) return;
-  if (a.mask && !a.mask[env]) return;
   const RCam& cam = a.cam;
   unsigned int* bits = (unsigned int*)(smem + a.off_bits);
   const int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;
@@ -783,6 +788,36 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
   }
 }
 
+template <bool THICK, int FMT>
+__global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int env = a.env0 + blockIdx.x;
+  if (env >= a.N) return;
+  if (a.mask && !a.mask[env]) return;
+  raster_body<THICK, FMT>(a, smem, env);
+}
+
+// Both stages in one launch: the same wavefront simulates its env and then rasterises it.  Saves one kernel
+// boundary (launch gap + one ramp-up / drain of the whole grid) per step.
+template <int K, bool THICK, int FMT>
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 8 ? 3 : 2)) void tc_step_kernel(KArgs a, RArgs r, int mode, const void* car_control,
+                                                                     int cdtype, const int* maneuver, const int* spawn_nodes,
+                                                                     const unsigned char* mask, unsigned int flags) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int env = a.env0 + blockIdx.x;
+  if (env >= a.N) return;
+  if (!sim_body<K>(a, smem, env, mode, car_control, cdtype, maneuver, spawn_nodes, mask, flags)) return;
+  __syncthreads();  // draw list + count written by this wavefront are visible to it (vmcnt(0) + barrier)
+  raster_body<THICK, FMT>(r, smem, env);
+}
+
+typedef void (*fused_kern_t)(KArgs, RArgs, int, const void*, int, const int*, const int*, const unsigned char*, unsigned int);
+template <int K>
+static fused_kern_t pick_fused(bool thick, bool cls) {
+  return thick ? (cls ? tc_step_kernel<K, true, TC_FMT_CLASSES> : tc_step_kernel<K, true, TC_FMT_RGB>)
+               : (cls ? tc_step_kernel<K, false, TC_FMT_CLASSES> : tc_step_kernel<K, false, TC_FMT_RGB>);
+}
+
 // =============================================================================================
 // Host side: C ABI
 // =============================================================================================
@@ -818,6 +853,7 @@ struct tc_env {
   // Measured on MI355X (cfg3): n=1 91.7 us, n=2 106.3 us, n=4 134.2 us -- the event fork/join costs more than
   // the overlap gains, so it stays off.
   int split;
+  int fuse;  // 1: simulate + raster in one launch (tc_step_kernel); 0: two launches
   hipStream_t side[TC_MAX_SPLIT];
   hipEvent_t fork_ev, join_ev[TC_MAX_SPLIT];
   // optional per-kernel timing: a ring of (start, mid, end) HIP events recorded on the caller's stream
@@ -1016,6 +1052,8 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   e->prof_calls = 0;
   memset(e->ev, 0, sizeof(e->ev));
   e->split = 1;
+  e->fuse = 1;
+  if (const char* fu = getenv("TC_FUSE")) e->fuse = atoi(fu) != 0;
   if (const char* sp = getenv("TC_SPLIT")) {
     int v = atoi(sp);
     if (v >= 1 && v <= TC_MAX_SPLIT) e->split = v;
@@ -1087,6 +1125,16 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
     set_err("tc_env_create: map too large for one workgroup's LDS");
     delete e;
     return TC_E_LDS;
+  }
+  {
+    const int lds = L.total > e->r_lds ? L.total : e->r_lds;
+    if (lds > 48 * 1024) {
+      for (int t = 0; t < 2; t++)
+        for (int c = 0; c < 2; c++) {
+          (void)hipFuncSetAttribute((const void*)pick_fused<5>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          (void)hipFuncSetAttribute((const void*)pick_fused<8>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        }
+    }
   }
   if (e->r_lds > 48 * 1024) {
     (void)hipFuncSetAttribute((const void*)tc_raster_kernel<true, TC_FMT_CLASSES>, hipFuncAttributeMaxDynamicSharedMemorySize, e->r_lds);
@@ -1211,51 +1259,55 @@ extern "C" int tc_env_set_camera(tc_env* e, const tc_camera_params* cam) {
   return rc;
 }
 
-static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
-                         void* stream, int env0 = 0, int count = -1) {
-  {
-    RArgs r;
-    memset(&r, 0, sizeof(r));
-    r.N = e->k.N;
-    r.env0 = env0;
-    if (count < 0) count = e->k.N;
-    r.C = e->k.m.C;
-    const DevCam& c = e->k.cam;
-    r.cam.H = c.H; r.cam.W = c.W; r.cam.wpr = c.wpr; r.cam.band_rows = c.band_rows; r.cam.n_bands = c.n_bands;
-    r.cam.thickness = c.thickness; r.cam.format = c.format;
-    {  // Circle(center, radius, fill) of drawing.cpp run once on the host: per-row half widths
-      int radius = (int)((((long long)c.thickness << 15) + 32768) >> 16);
-      r.cam.cap_r = radius;
-      if (radius < 32) {
-        int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
-        while (dx >= dy) {
-          if (r.cam.cap_hw[dy] < dx) r.cam.cap_hw[dy] = (unsigned char)dx;
-          if (r.cam.cap_hw[dx] < dy) r.cam.cap_hw[dx] = (unsigned char)dy;
-          dy++;
-          err += plus;
-          plus += 2;
-          int mask = (err <= 0) - 1;
-          err -= minus & mask;
-          dx += mask;
-          minus -= mask & 2;
-        }
+static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
+                        int env0) {
+  RArgs r;
+  memset(&r, 0, sizeof(r));
+  r.N = e->k.N;
+  r.env0 = env0;
+  r.C = e->k.m.C;
+  const DevCam& c = e->k.cam;
+  r.cam.H = c.H; r.cam.W = c.W; r.cam.wpr = c.wpr; r.cam.band_rows = c.band_rows; r.cam.n_bands = c.n_bands;
+  r.cam.thickness = c.thickness; r.cam.format = c.format;
+  {  // Circle(center, radius, fill) of drawing.cpp run once on the host: per-row half widths
+    int radius = (int)((((long long)c.thickness << 15) + 32768) >> 16);
+    r.cam.cap_r = radius;
+    if (radius < 32) {
+      int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+      while (dx >= dy) {
+        if (r.cam.cap_hw[dy] < dx) r.cam.cap_hw[dy] = (unsigned char)dx;
+        if (r.cam.cap_hw[dx] < dy) r.cam.cap_hw[dx] = (unsigned char)dy;
+        dy++;
+        err += plus;
+        plus += 2;
+        int mask2 = (err <= 0) - 1;
+        err -= minus & mask2;
+        dx += mask2;
+        minus -= mask2 & 2;
       }
     }
-    memcpy(r.colors, e->k.m.colors, sizeof(r.colors));
-    r.seg_g = seg_g;
-    r.seg_n = seg_n;
-    r.seg_cap = seg_cap;
-    r.obs = e->k.b.obs;
-    r.mask = mask;
-    r.off_tab = e->r_off_tab;
-    r.off_bits = e->r_off_bits;
-    r.flags = flags;
-    const bool thick = c.thickness > 1, cls = c.format == TC_FMT_CLASSES;
-    auto kern = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
-                      : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
-    hipLaunchKernelGGL(kern, dim3(count), dim3(TC_NT), e->r_lds, (hipStream_t)stream, r);
-    HIP_TRY(hipGetLastError());
   }
+  memcpy(r.colors, e->k.m.colors, sizeof(r.colors));
+  r.seg_g = seg_g;
+  r.seg_n = seg_n;
+  r.seg_cap = seg_cap;
+  r.obs = e->k.b.obs;
+  r.mask = mask;
+  r.off_tab = e->r_off_tab;
+  r.off_bits = e->r_off_bits;
+  r.flags = flags;
+  return r;
+}
+
+static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
+                         void* stream, int env0 = 0, int count = -1) {
+  RArgs r = make_rargs(e, seg_g, seg_n, seg_cap, mask, flags, env0);
+  if (count < 0) count = e->k.N;
+  const bool thick = r.cam.thickness > 1, cls = r.cam.format == TC_FMT_CLASSES;
+  auto kern = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
+                    : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
+  hipLaunchKernelGGL(kern, dim3(count), dim3(TC_NT), e->r_lds, (hipStream_t)stream, r);
+  HIP_TRY(hipGetLastError());
   return TC_OK;
 }
 
@@ -1281,6 +1333,23 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   hipStream_t main = (hipStream_t)stream;
   if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], main));
   if (parts > 1) HIP_TRY(hipEventRecord(e->fork_ev, main));
+  if (do_raster && e->fuse && parts == 1 && big <= 8 * TC_NT) {  // one launch: simulate + raster by the same wavefront
+    // (maps beyond 512 nodes/edges use the register-hungry K = 13 simulate stage: fused it spills, so two launches)
+    const bool thick = e->k.cam.thickness > 1, cls = e->k.cam.format == TC_FMT_CLASSES;
+    fused_kern_t fk = big <= 5 * TC_NT ? pick_fused<5>(thick, cls) : pick_fused<8>(thick, cls);
+    KArgs k = e->k;
+    k.env0 = 0;
+    RArgs r = make_rargs(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, nullptr, flags, 0);
+    const int lds = e->k.lds.total > e->r_lds ? e->k.lds.total : e->r_lds;
+    hipLaunchKernelGGL(fk, dim3(N), dim3(TC_NT), lds, main, k, r, mode, cc, cdtype, man, spawn, mask, flags);
+    HIP_TRY(hipGetLastError());
+    if (prof) {  // one kernel: its whole duration is reported as the first interval, the second is empty
+      HIP_TRY(hipEventRecord(e->ev[1][slot], main));
+      HIP_TRY(hipEventRecord(e->ev[2][slot], main));
+      e->prof_n++;
+    }
+    return TC_OK;
+  }
   for (int p = 0; p < parts; p++) {
     const int env0 = (int)((long long)N * p / parts), env1 = (int)((long long)N * (p + 1) / parts);
     hipStream_t st = p == 0 ? main : e->side[p];

@@ -10,7 +10,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}", "p*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         if "tc_" in r["Kernel_Name"]:
-            k = "tc_raster_kernel" if "tc_raster" in r["Kernel_Name"] else "tc_env_kernel"
+            k = "tc_step_kernel" if "tc_step_kernel" in r["Kernel_Name"] else ("tc_raster_kernel" if "tc_raster" in r["Kernel_Name"] else "tc_env_kernel")
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 res["_note"] = "per-launch means over the profiled launches; FETCH_SIZE/WRITE_SIZE in KB as rocprofv3 reports them"
