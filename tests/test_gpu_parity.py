@@ -374,3 +374,27 @@ def test_large_synthetic_map_multi_window(tmp_path):
             assert_same(env, o, env.n_classes, label=f"big map {fmt} step {t}")
         assert int(env.out["obs"].max()) > 0
         env.close()
+
+
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_two_launch_and_fused_paths_agree_with_oracle(fuse, monkeypatch):
+    """TC_FUSE=0 (tc_env_kernel + tc_raster_kernel) and the default fused tc_step_kernel are the same computation."""
+    monkeypatch.setenv("TC_FUSE", fuse)
+    N = 192
+    env = make_env("simple_layout", "r64", "classes", N, autoreset=True, spawn_queue_len=4)
+    o = make_oracle(env)
+    env.reset(seed=31)
+    o.spawn_queue = env._aux["spawn_queue"].cpu().numpy()
+    o.reset(env._keep[0].cpu().numpy())
+    rng = np.random.default_rng(4)
+    env.profile(2)  # also exercises the event path of the chosen launch mode
+    for t in range(16):
+        cc = np.stack([rng.uniform(-0.2, 1.1, N), rng.uniform(-1.1, 1.1, N)], axis=1).astype(np.float32)
+        man = rng.integers(0, 4, N).astype(np.int32)
+        o.step(cc.astype(np.float64), man, flags=orc.F_AUTORESET)
+        env.step({"car_control": cc, "maneuver": man})
+        assert_same(env, o, env.n_classes, label=f"fuse={fuse} step {t}")
+    p = env.profile_read()
+    assert p["launches"] == 8 and p["simulate_us"] > 0
+    assert (p["raster_us"] < 0.25 * p["simulate_us"]) == (fuse == "1")
+    env.close()
