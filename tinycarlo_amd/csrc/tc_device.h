@@ -430,7 +430,7 @@ __device__ inline int d_wrap32(long long v) { return (int)(unsigned int)(unsigne
 // work they skip; an out-of-window pixel ORs 0 into word 0 of the plane instead.
 __device__ inline void r_put(const Ras& r, int x, int y) {
   const bool ok = (unsigned)x < (unsigned)r.W && (unsigned)(y - r.y0) < (unsigned)(r.y1 - r.y0);
-  const int idx = ok ? (y - r.y0) * r.wpr + (x >> 5) : 0;
+  const int idx = ok ? __mul24(y - r.y0, r.wpr) + (x >> 5) : 0;  // rows, words per row < 2^24: full-rate multiply
   atomicOr(&r.bits[idx], ok ? 1u << (x & 31) : 0u);
 }
 
@@ -441,7 +441,7 @@ __device__ inline void r_hline(const Ras& r, int y, int xl, int xr) {
   const bool ok = (unsigned)(y - r.y0) < (unsigned)(r.y1 - r.y0) && xl <= xr;
   const int w0 = xl >> 5;
   const int w1 = ok ? xr >> 5 : w0 - 1;
-  unsigned int* row = r.bits + (ok ? (y - r.y0) * r.wpr : 0);
+  unsigned int* row = r.bits + (ok ? __mul24(y - r.y0, r.wpr) : 0);
   for (int w = w0; w <= w1; w++) {
     const int lo = w == w0 ? (xl & 31) : 0;
     const int hi = w == w1 ? (xr & 31) : 31;
@@ -614,12 +614,10 @@ __device__ inline LineP r_line2_setup(int W, int H, long long p1x, long long p1y
 // steps k0..k1 (inclusive) of an outline edge
 __device__ inline void r_line2_pixels(const Ras& r, int a, int b, int step, int xmajor, int k0, int k1) {
   int major = a + k0;
-  int minor = b + k0 * step;
+  int minor = b + __mul24(k0, step);  // k0 <= 16384 (frame size limit), |step| <= 65536: exact in 24x24 bits
   for (int k = k0; k <= k1; k++) {
-    if (xmajor)
-      r_put(r, major, minor >> TC_XY_SHIFT);
-    else
-      r_put(r, minor >> TC_XY_SHIFT, major);
+    const int mn = minor >> TC_XY_SHIFT;
+    r_put(r, xmajor ? major : mn, xmajor ? mn : major);  // selects, not a divergent branch per pixel
     major++;
     minor += step;
   }
