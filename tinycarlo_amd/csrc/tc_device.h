@@ -463,36 +463,62 @@ __device__ inline void r_cap(const Ras& r, int cx, int cy, int rad, const unsign
 // clipLine(Size2l, Point2l&, Point2l&)
 __device__ inline bool r_clip_line(long long width, long long height, long long& x1, long long& y1, long long& x2,
                                    long long& y2) {
+  // clipLine() clips end 1 against the y range, then end 2 (against the already clipped end 1), then the same for x.
+  // Under SIMT each of those four blocks (an f64 multiply + divide between int64 conversions) would be executed by
+  // the whole wave as soon as one lane needs it.  Here ONE instance per axis serves whichever end needs it -- roles
+  // are swapped for lanes where only end 2 does; (a-y2)*(x1-x2)/(y1-y2) equals (a-y2)*(x2-x1)/(y2-y1) bit for bit
+  // because IEEE multiplication and division are sign-symmetric -- and a second instance runs only for lanes where
+  // both ends need clipping on that axis (rare; skipped by the whole wave otherwise).
   int c1, c2;
   long long right = width - 1, bottom = height - 1;
   if (width <= 0 || height <= 0) return false;
   c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
   c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
   if ((c1 & c2) == 0 && (c1 | c2) != 0) {
-    long long a;
-    if (c1 & 12) {
-      a = c1 < 8 ? 0 : bottom;
-      x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
-      y1 = a;
-      c1 = (x1 < 0) + (x1 > right) * 2;
-    }
-    if (c2 & 12) {
-      a = c2 < 8 ? 0 : bottom;
-      x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
-      y2 = a;
-      c2 = (x2 < 0) + (x2 > right) * 2;
+    const bool n1 = (c1 & 12) != 0, n2 = (c2 & 12) != 0;
+    if (n1 || n2) {
+      const bool sw = !n1;  // only end 2 needs it: treat it as "the end to clip"
+      long long xa = sw ? x2 : x1, ya = sw ? y2 : y1, xb = sw ? x1 : x2, yb = sw ? y1 : y2;
+      const int ca = sw ? c2 : c1;
+      const long long a = ca < 8 ? 0 : bottom;
+      xa += (long long)((double)(a - ya) * (double)(xb - xa) / (double)(yb - ya));
+      const int cn = (xa < 0) + (xa > right) * 2;
+      if (sw) {
+        x2 = xa;
+        y2 = a;
+        c2 = cn;
+      } else {
+        x1 = xa;
+        y1 = a;
+        c1 = cn;
+      }
+      if (n1 && n2) {  // both ends: end 2 against the clipped end 1
+        const long long a2 = c2 < 8 ? 0 : bottom;
+        x2 += (long long)((double)(a2 - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+        y2 = a2;
+        c2 = (x2 < 0) + (x2 > right) * 2;
+      }
     }
     if ((c1 & c2) == 0 && (c1 | c2) != 0) {
-      if (c1) {
-        a = c1 == 1 ? 0 : right;
-        y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+      const bool m1 = c1 != 0, m2 = c2 != 0;
+      const bool sw = !m1;
+      long long xa = sw ? x2 : x1, ya = sw ? y2 : y1, xb = sw ? x1 : x2, yb = sw ? y1 : y2;
+      const int ca = sw ? c2 : c1;
+      const long long a = ca == 1 ? 0 : right;
+      ya += (long long)((double)(a - xa) * (double)(yb - ya) / (double)(xb - xa));
+      if (sw) {
+        x2 = a;
+        y2 = ya;
+        c2 = 0;
+      } else {
         x1 = a;
+        y1 = ya;
         c1 = 0;
       }
-      if (c2) {
-        a = c2 == 1 ? 0 : right;
-        y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
-        x2 = a;
+      if (m1 && m2) {
+        const long long a2 = c2 == 1 ? 0 : right;
+        y2 += (long long)((double)(a2 - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+        x2 = a2;
         c2 = 0;
       }
     }
@@ -687,7 +713,7 @@ __device__ inline int r_fill_events(int W, int H, long long qx0, long long qx1, 
         const int di = i ? npts - 1 : 1;
         int idx = idx0 + di;
         if (idx >= npts) idx -= npts;
-        for (; edges-- > 0;) {
+        for (; edges-- > 0;) {  // (a straight-line 4-candidate version of this scan was tried: 25 % more instructions)
           int ty = idx == 0 ? ty0 : idx == 1 ? ty1 : idx == 2 ? ty2 : ty3;
           if (ty > y) {
             py[np] = y;

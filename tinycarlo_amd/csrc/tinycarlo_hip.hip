@@ -36,6 +36,10 @@
 #define DBG_SKIP_R2 0x1000u
 #define DBG_SKIP_R3 0x2000u
 #define DBG_SKIP_R4 0x4000u
+#define DBG_SKIP_EVENTS 0x10000u
+#define DBG_SKIP_LINESETUP 0x20000u
+#define DBG_SKIP_SLOPE 0x40000u
+#define DBG_SKIP_QUAD 0x80000u
 
 #define RB 32        // segments rasterised per batch
 #define LCH 8        // outline steps per chunk
@@ -563,11 +567,12 @@ __device__ inline void raster_body(const RArgs& a, unsigned char* smem, int env)
           if (tid < nb) {
             const int* sg = segg + 5 * (base + tid);
             long long qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3;
-            if (r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
+            if (!(a.flags & DBG_SKIP_QUAD) && r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
               okq = 1;
               dpx = (int)(qx0 - (long long)sg[1] * TC_XY_ONE);
               dpy = (int)(qy0 - (long long)sg[2] * TC_XY_ONE);
               int hi;
+              if (!(a.flags & DBG_SKIP_EVENTS))
               np = r_fill_events(W, H, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, fpy + 4 * tid, fpv + 4 * tid, wm, lo,
                                  hi);
               if (lo < y0) lo = y0;
@@ -595,13 +600,15 @@ __device__ inline void raster_body(const RArgs& a, unsigned char* smem, int env)
             // FillConvexPoly walks p0 = v[3]; Line2(p0, v[i]); p0 = v[i]
             long long ax = sel4(qx3, qx0, qx1, qx2, e), ay = sel4(qy3, qy0, qy1, qy2, e);
             long long bx = sel4(qx0, qx1, qx2, qx3, e), by = sel4(qy0, qy1, qy2, qy3, e);
-            if (e < (fm[j] & 0xff)) {  // fill piece e of this segment: x at its start row and slope
+            if (e < (fm[j] & 0xff) && !(a.flags & DBG_SKIP_SLOPE)) {  // fill piece e of this segment: x at its start row and slope
               long long xs, dxs;
               r_fill_slope(qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, fpy[t], fpv[t], xs, dxs);
               fpx[t] = xs;
               fpd[t] = dxs;
             }
-            LineP L = r_line2_setup(W, H, ax, ay, bx, by);
+            LineP L;
+            L.ecount = -1;
+            if (!(a.flags & DBG_SKIP_LINESETUP)) L = r_line2_setup(W, H, ax, ay, bx, by);
             if (L.ecount >= 0) {
               r.bits = bits + sg[0] * plane;
               r_put(r, L.ex, L.ey);
