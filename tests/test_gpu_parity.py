@@ -156,7 +156,8 @@ def test_golden_single_steps(mp):
 
 CASES = [
     # (map, resolution key, format, N envs, steps, thickness)
-    ("simple_layout", "r64", "classes", 512, 96, 2),     # BASELINE config 3 shape
+    ("simple_layout", "r64", "classes", 4096, 64, 2),    # BASELINE config 3 at its full size
+    ("simple_layout", "r64", "classes", 512, 96, 2),
     ("knuffingen", "r128", "classes", 256, 64, 2),       # BASELINE config 4 shape
     ("simple_layout", "r64", "rgb", 128, 48, 2),
     ("knuffingen", "r64", "classes", 128, 48, 1),        # thickness 1: Bresenham path

@@ -42,6 +42,10 @@
 #define DBG_SKIP_QUAD 0x80000u
 
 #define RB 32        // segments rasterised per batch
+// raster-stage LDS layout (compile-time: folds into instruction offsets and frees SGPRs)
+#define R_OFF_TAB 0
+#define R_TAB_BYTES ((RB * 4 * 5 + RB * 4 + 5 * RB + 8 * RB) * 4 + 2 * 4 * RB * 8)
+#define R_OFF_BITS ((R_TAB_BYTES + 15) / 16 * 16)
 #define LCH 8        // outline steps per chunk
 
 struct LdsLayout {
@@ -515,7 +519,7 @@ template <bool THICK, int FMT>
 __device__ inline void raster_body(const RArgs& a, unsigned char* smem, int env) {
   const int tid = threadIdx.x;
   const RCam& cam = a.cam;
-  unsigned int* bits = (unsigned int*)(smem + a.off_bits);
+  unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
   const int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;
   const int nseg = a.seg_n[env];
   unsigned int used_layers = 0;  // layers that have at least one segment in this frame (wave-uniform)
@@ -525,7 +529,7 @@ __device__ inline void raster_body(const RArgs& a, unsigned char* smem, int env)
 
   const int H = cam.H, W = cam.W, wpr = cam.wpr, C = a.C;
   unsigned char* out = a.obs + (size_t)env * ((size_t)H * W * (FMT == TC_FMT_CLASSES ? C : 3));
-  int* lt = (int*)(smem + a.off_tab);     // [RB*4][5] outline-edge parameters
+  int* lt = (int*)(smem + R_OFF_TAB);     // [RB*4][5] outline-edge parameters
   int* lc = lt + RB * 4 * 5;              // [RB*4] chunks per outline edge, then exclusive prefix
   int* fl = lc + RB * 4;                  // [RB] first fill row of the segment in this band
   int* fc = fl + RB;                      // [RB] fill rows, then exclusive prefix
@@ -1125,8 +1129,8 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   off += 64;
   L.total = off;
   // raster kernel: tables + bit-planes of one band
-  e->r_off_tab = 0;
-  e->r_off_bits = align_up((RB * 4 * 5 + RB * 4 + 5 * RB + 8 * RB) * 4 + 2 * 4 * RB * 8, 16);
+  e->r_off_tab = R_OFF_TAB;
+  e->r_off_bits = R_OFF_BITS;
   e->r_lds = e->r_off_bits + align_up(m.C * band_rows * dc.wpr * 4, 16);
   if (L.total > 160 * 1024 || e->r_lds > 160 * 1024) {
     set_err("tc_env_create: map too large for one workgroup's LDS");
