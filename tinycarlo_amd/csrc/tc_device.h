@@ -78,6 +78,7 @@ struct DevCam {
 
 struct CarState {
   double x, y, theta, velocity, steering, radius, front_x, front_y;
+  double cth, sth;  // cos(theta), sin(theta) of the current heading (not stored: recomputed when state is loaded)
   int lp[8];
   int lp_len, last_maneuver;
 };
@@ -254,8 +255,10 @@ __device__ inline int d_nearest_edge_with_orientation(const DevMap& m, double px
 
 // ------------------------------------------------------------------ car.py
 __device__ inline void d_update_front(const DevCar& c, CarState& s) {  // car.py:167-168
-  s.front_x = s.x + c.wheelbase * tc_cos(s.theta);
-  s.front_y = s.y + c.wheelbase * tc_sin(s.theta);
+  s.cth = tc_cos(s.theta);
+  s.sth = tc_sin(s.theta);
+  s.front_x = s.x + c.wheelbase * s.cth;
+  s.front_y = s.y + c.wheelbase * s.sth;
 }
 
 // car.py:34-44 + map.py:62-69 with the spawn node already drawn
@@ -371,6 +374,12 @@ __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, 
     s.radius = 0;
     s.x = s.x + s.velocity * vxn * dt;
     s.y = s.y + s.velocity * vyn * dt;
+    // heading unchanged: car.py:167-168 evaluates cos/sin of the same angle again
+    s.cth = vxn;
+    s.sth = vyn;
+    s.front_x = s.x + c.wheelbase * vxn;
+    s.front_y = s.y + c.wheelbase * vyn;
+    return d_find_local_path(m, s, maneuver, status, pi);
   } else {
     s.radius = c.wheelbase / tc_tan(d_radians(s.steering));
     double ang_vel = s.velocity / s.radius;

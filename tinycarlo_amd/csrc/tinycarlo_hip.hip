@@ -245,6 +245,7 @@ __device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, in
   s.last_maneuver = b.last_maneuver[env];
 
   int status = 0, trunc = 0;
+  bool have_trig = false;  // s.cth / s.sth hold cos / sin of the current heading
   PathInfo pinfo;
   pinfo.ax = pinfo.ay = pinfo.bx = pinfo.by = pinfo.ori = 0;
   pinfo.valid = 0;
@@ -252,12 +253,14 @@ __device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, in
   if (mode == MODE_RESET) {
     d_reset(m, a.car, s, checked_spawn(m, spawn_nodes[env], status));
     fresh = true;
+    have_trig = true;
   } else if (mode == MODE_STEP) {
     if ((flags & TC_F_AUTORESET) && b.needs_reset[env]) {
       int cur = b.spawn_cursor[env];
       int node = b.spawn_queue[(size_t)env * b.spawn_queue_len + ((unsigned)cur % (unsigned)b.spawn_queue_len)];
       d_reset(m, a.car, s, checked_spawn(m, node, status));
       fresh = true;
+      have_trig = true;
       if (tid == 0) b.spawn_cursor[env] = cur + 1;
     } else if ((unsigned)s.lp[0] >= (unsigned)m.lpN || (unsigned)s.lp[1] >= (unsigned)m.lpN) {
       status |= TC_S_NOT_RESET;  // stepping an env that was never reset: no valid lanepath edge to index with
@@ -274,6 +277,7 @@ __device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, in
       v = d_np_clip(v, -1.0, 1.0);  // env.py:118
       st = d_np_clip(st, -1.0, 1.0);
       trunc = d_car_step(m, a.car, s, v, st, maneuver[env], status, pinfo);
+      have_trig = true;
     }
   }
 
@@ -396,7 +400,16 @@ __device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, in
     for (int i = 0; i < 12; i++) Ec[i] = a.cam_E ? a.cam_E[(size_t)env * 12 + i] : cam.E[i];
 #pragma unroll
     for (int i = 0; i < 9; i++) Kc[i] = a.cam_K ? a.cam_K[(size_t)env * 9 + i] : cam.K[i];
-    double cth = tc_cos(-s.theta), sth = tc_sin(-s.theta);  // car.py:159-165
+    // car.py:159-165 needs cos(-theta), sin(-theta).  tc_cos is exactly even and tc_sin exactly odd (their kernels
+    // are built from x*x and x*y terms only), so the values of the front-axle update are reused bit for bit.
+    double cth, sth;
+    if (have_trig) {
+      cth = s.cth;
+      sth = -s.sth;
+    } else {
+      cth = tc_cos(-s.theta);
+      sth = tc_sin(-s.theta);
+    }
     double R[16] = {cth, -sth, 0, 0, sth, cth, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     double Tm[16] = {1, 0, 0, -s.x, 0, 1, 0, -s.y, 0, 0, 1, 0, 0, 0, 0, 1};
     double car3d[16];
