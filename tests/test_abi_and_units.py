@@ -138,3 +138,52 @@ def test_raster_clips_huge_coordinates_and_rgb_colour_order():
     assert out.sum() == 0
     edge = orc.polyline(_img(8, 8), (0, 0), (7, 0), 255, 6)             # caps and quad clipped at the border
     assert edge[0].all() and edge[3].all() and not edge[4:].any()
+
+
+# ------------------------------------------------------------------ C ABI error behaviour (no GPU needed: validation comes first)
+def _desc(n_layers, node_count, edge_count, nodes, edges, lp_nodes, lp_edges):
+    from tinycarlo_amd import _native as n
+    keep = dict(nc=np.array(node_count, np.int32), ec=np.array(edge_count, np.int32), nd=np.array(nodes, np.float64),
+                ed=np.array(edges, np.int32), col=np.zeros((max(n_layers, 1), 3), np.uint8),
+                ln=np.array(lp_nodes, np.float64), le=np.array(lp_edges, np.int32).reshape(-1, 2))
+    d = n.MapDesc(n_layers, keep["nc"].ctypes.data_as(n._ip), keep["ec"].ctypes.data_as(n._ip),
+                  keep["nd"].ctypes.data_as(n._dp), keep["ed"].ctypes.data_as(n._ip), keep["col"].ctypes.data_as(n._bp),
+                  len(keep["ln"]), len(keep["le"]), keep["ln"].ctypes.data_as(n._dp), keep["le"].ctypes.data_as(n._ip))
+    return d, keep
+
+
+def test_map_create_rejects_bad_descriptions():
+    from tinycarlo_amd import _native as n
+    L = n.lib()
+    h = C.c_void_p()
+    good = dict(node_count=[2], edge_count=[1], nodes=[[0, 0], [1, 0]], edges=[[0, 1]], lp_nodes=[[0, 0], [1, 0]], lp_edges=[[0, 1]])
+    cases = {
+        "no layers": dict(good, n_layers=0),
+        "too many layers": dict(good, n_layers=17, node_count=[2] * 17, edge_count=[1] * 17),
+        "edge to missing node": dict(good, n_layers=1, edges=[[0, 5]]),
+        "lanepath edge to missing node": dict(good, n_layers=1, lp_edges=[[0, 9]]),
+        "lanepath without edges": dict(good, n_layers=1, lp_edges=np.zeros((0, 2), np.int32)),
+    }
+    for name, c in cases.items():
+        nl = c.pop("n_layers")
+        d, keep = _desc(nl, **c)
+        rc = L.tc_map_create(C.byref(d), C.byref(h))
+        assert rc == -1, (name, rc)          # TC_E_INVALID
+    assert L.tc_map_create(None, C.byref(h)) == -1
+    assert b"lanepath" in L.tc_last_error() or L.tc_last_error() is not None
+
+
+def test_null_handles_are_rejected_not_dereferenced():
+    from tinycarlo_amd import _native as n
+    L = n.lib()
+    h = C.c_void_p()
+    assert L.tc_env_create(None, None, None, 4, C.byref(h)) == -1
+    assert L.tc_env_bind(None, None) == -1
+    assert L.tc_step(None, None, 0, None, 0, None) == -1
+    assert L.tc_reset(None, None, None, 0, None) == -1
+    assert L.tc_env_set_camera(None, None) == -1
+    assert L.tc_env_set_camera_per_env(None, None, None) == -1
+    assert L.tc_render_segments(None, None, None, 0, None) == -1
+    assert L.tc_env_profile(None, 1) == -1
+    assert L.tc_env_obs_bytes(None) == -1 and L.tc_env_lds_bytes(None) == -1
+    assert L.tc_env_destroy(None) == 0 and L.tc_map_destroy(None) == 0

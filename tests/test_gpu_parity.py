@@ -399,3 +399,38 @@ def test_two_launch_and_fused_paths_agree_with_oracle(fuse, monkeypatch):
     assert p["launches"] == 8 and p["simulate_us"] > 0
     assert (p["raster_us"] < 0.25 * p["simulate_us"]) == (fuse == "1")
     env.close()
+
+
+def test_abi_error_paths_on_device():
+    """status codes instead of crashes: step before bind / before reset, bad spawn nodes, bad dtypes"""
+    import ctypes as C
+    from tinycarlo_amd import _native as nat
+    env = make_env("simple_layout", "r64", "classes", 8)
+    L = nat.lib()
+    # a second handle that is never bound
+    h = C.c_void_p()
+    cp = nat.make_car_params(env.car_params)
+    cam = nat.make_camera_params(env.camera, nat.FMT_CLASSES)
+    nat.check(L.tc_env_create(env._nmap.handle, C.byref(cp), C.byref(cam), 8, C.byref(h)), "tc_env_create")
+    cc = torch.zeros((8, 2), dtype=torch.float32, device="cuda:0")
+    mn = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    assert L.tc_step(h, cc.data_ptr(), nat.F32, mn.data_ptr(), 0, None) == -4          # TC_E_UNBOUND
+    assert L.tc_step(env._h, cc.data_ptr(), 7, mn.data_ptr(), 0, None) == -1           # bad dtype
+    bad = nat.make_camera_params(env.camera, nat.FMT_CLASSES)
+    bad.width = 32
+    assert L.tc_env_set_camera(env._h, C.byref(bad)) == -1                             # resolution is fixed
+    L.tc_env_destroy(h)
+    # stepping envs that were never reset: truncated + TC_S_NOT_RESET, nothing faults
+    env._was_reset = True
+    env.step({"car_control": cc, "maneuver": mn})
+    torch.cuda.synchronize()
+    assert bool(env.out["truncated"].all()) and bool(((env.out["status"] & nat.S_NOT_RESET) != 0).all())
+    # out-of-range / sink spawn nodes are replaced and flagged
+    sinks = [i for i in range(len(env.map.lanepath.nodes)) if not env.map._has_next()[i]]
+    nodes = np.array([-5, 10 ** 6, sinks[0], 3, 4, 5, 6, 7], dtype=np.int32)
+    env.reset_to(nodes)
+    torch.cuda.synchronize()
+    st = env.out["status"].cpu().numpy()
+    assert (st[:3] & nat.S_BAD_SPAWN).all() and not (st[3:] & nat.S_BAD_SPAWN).any()
+    assert int(env.state["lp_len"].min()) == 1 and int(env.state["local_path"][:, 0].min()) >= 0
+    env.close()
