@@ -576,14 +576,20 @@ __device__ inline void r_line_bresenham(const Ras& r, long long x1, long long y1
   }
 }
 
-// Truncating int64 division n / d (C semantics) through one correctly rounded f64 division when both
-// operands are below 2^52 (always the case after clipping); ~3x cheaper than the 64-bit integer
-// division sequence and exact: RN(n/d) can only overshoot floor(n/d) by one, which the remainder test undoes.
+// Truncating int64 division n / d (C semantics) for operands below 2^50 (always the case after clipping):
+// several times cheaper than the 64-bit integer division sequence.
 __device__ inline long long d_sdiv(long long n, long long d) {
   long long an = n < 0 ? -n : n, ad = d < 0 ? -d : d;
-  if (an < (1LL << 52) && ad < (1LL << 52)) {
-    long long q = (long long)((double)an / (double)ad);
-    if (an - q * ad < 0) q--;
+  if (an < (1LL << 50) && ad < (1LL << 50)) {
+    // quotient estimate from a hardware reciprocal (relative error ~2^-50: off by at most one for an < 2^50),
+    // made exact by the remainder test -- the result is the true integer quotient, no rounding mode involved
+    long long q = (long long)((double)an * __builtin_amdgcn_rcp((double)ad));
+    long long r = an - q * ad;
+    if (r < 0) {
+      q--;
+      r += ad;
+    }
+    if (r >= ad) q++;
     return ((n < 0) != (d < 0)) ? -q : q;
   }
   return n / d;

@@ -614,9 +614,12 @@ __device__ inline void raster_body(const RArgs& a, unsigned char* smem, int env)
             const long long dpx = fd[2 * j], dpy = fd[2 * j + 1];
             const long long qx0 = p0x + dpx, qx1 = p0x - dpx, qx2 = p1x - dpx, qx3 = p1x + dpx;
             const long long qy0 = p0y + dpy, qy1 = p0y - dpy, qy2 = p1y - dpy, qy3 = p1y + dpy;
-            // FillConvexPoly walks p0 = v[3]; Line2(p0, v[i]); p0 = v[i]
-            long long ax = sel4(qx3, qx0, qx1, qx2, e), ay = sel4(qy3, qy0, qy1, qy2, e);
-            long long bx = sel4(qx0, qx1, qx2, qx3, e), by = sel4(qy0, qy1, qy2, qy3, e);
+            // FillConvexPoly walks p0 = v[3]; Line2(p0, v[i]); p0 = v[i]: outline edge e runs v[e-1] -> v[e] with
+            // v0 = p0+dp, v1 = p0-dp, v2 = p1-dp, v3 = p1+dp
+            const bool a_is_p1 = e == 0 || e == 3, b_is_p1 = e >= 2;
+            const bool a_minus = e == 2 || e == 3, b_minus = e == 1 || e == 2;
+            long long ax = (a_is_p1 ? p1x : p0x) + (a_minus ? -dpx : dpx), ay = (a_is_p1 ? p1y : p0y) + (a_minus ? -dpy : dpy);
+            long long bx = (b_is_p1 ? p1x : p0x) + (b_minus ? -dpx : dpx), by = (b_is_p1 ? p1y : p0y) + (b_minus ? -dpy : dpy);
             if (e < (fm[j] & 0xff) && !(a.flags & DBG_SKIP_SLOPE)) {  // fill piece e of this segment: x at its start row and slope
               long long xs, dxs;
               r_fill_slope(qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, fpy[t], fpv[t], xs, dxs);
