@@ -11,7 +11,8 @@ from tinycarlo_amd.map import Map
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RES = {"r64": [64, 64], "r128": [128, 128], "r480": [480, 640]}
-CFG = {"simple_layout": "config_simple_layout.yaml", "knuffingen": "config_knuffingen.yaml"}
+CFG = {"simple_layout": "config_simple_layout.yaml", "knuffingen": "config_knuffingen.yaml",
+       "formula_student_track": "config_formula_student_track.yaml"}
 
 _cache = {}
 
@@ -45,7 +46,10 @@ def rollout_files():
 
 
 def map_of(fname):
-    return "simple_layout" if "simple_layout" in fname else "knuffingen"
+    for name in CFG:
+        if name in fname:
+            return name
+    raise KeyError(fname)
 
 
 def cam_keys(d):

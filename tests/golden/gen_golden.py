@@ -78,14 +78,26 @@ MAPS = {
     "simple_layout": "config_simple_layout.yaml",
     "knuffingen": "config_knuffingen.yaml",
 }
+# maps the reference ships without a config: driven with this repo's own config (tinycarlo_amd/data/), map file
+# taken from the reference
+EXTRA_MAPS = {
+    "formula_student_track": os.path.join(os.path.dirname(os.path.dirname(OUT)), "tinycarlo_amd", "data",
+                                          "config_formula_student_track.yaml"),
+}
 RESOLUTIONS = {"r64": [64, 64], "r128": [128, 128], "r480": [480, 640]}
 
 
 def load(map_name):
-    path = os.path.join(REF, "examples", MAPS[map_name])
-    with open(path) as f:
-        cfg = yaml.safe_load(f)
-    m = Map(cfg["map"], base_path=path)
+    if map_name in EXTRA_MAPS:
+        with open(EXTRA_MAPS[map_name]) as f:
+            cfg = yaml.safe_load(f)
+        path = os.path.join(REF, "examples", "x.yaml")  # json_path is relative to the reference's examples/
+        m = Map(cfg["map"], base_path=path)
+    else:
+        path = os.path.join(REF, "examples", MAPS[map_name])
+        with open(path) as f:
+            cfg = yaml.safe_load(f)
+        m = Map(cfg["map"], base_path=path)
     car = Car(1 / cfg["sim"].get("fps", 30), m, cfg["car"])
     ren = Renderer.__new__(Renderer)
     cams = {}
@@ -433,6 +445,16 @@ def camera_mats():
     return out
 
 
+def main_extra():
+    """formula_student_track rollouts (added later; the other fixtures are left untouched)"""
+    for mn, seed, steps, pol, cks, mp in [("formula_student_track", 0, 300, "stanley", ["r64"], 16),
+                                          ("formula_student_track", 1, 300, "random", ["r128"], 32)]:
+        out = rollout(mn, seed, steps, pol, cks, mp)
+        name = f"rollout_{mn}_{pol}_{seed}.npz"
+        np.savez_compressed(os.path.join(OUT, name), **out)
+        print(name, "resets", len(out["reset_step"]), "trunc", int(out["truncated"].sum()), "term", int(out["terminated"].sum()))
+
+
 def main():
     with open(os.path.join(OUT, "unit_vectors.json"), "w") as f:
         json.dump(unit_vectors(), f)
@@ -462,4 +484,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        main_extra()
+    else:
+        main()

@@ -88,9 +88,16 @@ def _check_batch(o, d, C, tol):
 def _check_segments(o, seg, segf, t_label, i=0):
     got_i, got_f = o.segments(i)
     assert got_i.shape == seg.shape, (t_label, got_i.shape, seg.shape)
-    assert np.array_equal(got_i, seg), (t_label, np.argwhere(got_i != seg)[:5])
-    # float end points can be ~1e8 px for nodes clipped to z=-1e-7: relative tolerance
+    # float end points can be ~1e8 px for nodes clipped to z=-1e-7 (camera.py:70-86): the new depth is a
+    # difference of O(0.1) numbers, so one ulp of the reference's BLAS matmul (FMA or not) is a 1e-10
+    # relative change of u = fx*X/z.  Hence a relative tolerance on the floats, and the truncated int32 of
+    # such a far-off end point may land on the neighbouring integer; every on-screen-sized value is exact.
     assert np.allclose(got_f, segf, rtol=1e-9, atol=1e-9), t_label
+    bad = got_i != seg
+    if bad.any():
+        far = np.abs(seg.astype(np.int64)) > (1 << 20)
+        assert not (bad & ~far).any(), (t_label, np.argwhere(bad & ~far)[:5])
+        assert np.abs(got_i.astype(np.int64) - seg)[bad].max() <= 1, (t_label, np.argwhere(bad)[:5])
 
 
 @pytest.mark.parametrize("mode,tol", [(orc.MATH_LIBM, FTOL), (orc.MATH_PORTABLE, 1e-9)])
@@ -146,8 +153,7 @@ def test_rollout_free_running(fname):
         _check_state(o, d, t, 1e-9)
         _check_info(o, d, t, C, 1e-9)
         lo, hi = d[f"seg_{k}_off"][t], d[f"seg_{k}_off"][t + 1]
-        got_i, _ = o.segments(0)
-        assert np.array_equal(got_i, d[f"seg_{k}"][lo:hi]), (fname, t)
+        _check_segments(o, d[f"seg_{k}"][lo:hi], d[f"segf_{k}"][lo:hi], (fname, t))
 
 
 @pytest.mark.parametrize("mode,tol", [(orc.MATH_LIBM, FTOL), (orc.MATH_PORTABLE, 1e-9)])
