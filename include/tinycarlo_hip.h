@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 1
+#define TC_ABI_VERSION 2
 #define TC_MAX_LAYERS 16
 
 /* error codes */
@@ -69,6 +69,27 @@ extern "C" {
 #define TC_S_PICK_EMPTY 2    /* neighbour list made only of self-loops (ValueError at layer.py:123): truncated */
 #define TC_S_BAD_SPAWN 4     /* spawn node out of range or without out-edge: first spawnable node used instead */
 #define TC_S_NOT_RESET 8     /* tc_step on an env that was never reset: truncated, state untouched */
+
+/* Reward / termination terms: the wrappers of tinycarlo/wrapper/reward.py and termination.py, evaluated in the
+ * epilogue of the step kernel in the order given (= the order the wrappers are stacked, innermost first; reward
+ * additions are floating point, so the order is part of the result). */
+#define TC_MAX_TERMS 8
+#define TC_T_LANELINE_SPARSE_REWARD 1       /* reward.py:5-23   per_layer = sparse_rewards[name], layer_mask = names present */
+#define TC_T_LANELINE_LINEAR_REWARD 2       /* reward.py:25-42  per_layer = max_rewards[name] (every layer) */
+#define TC_T_CTE_SPARSE_REWARD 3            /* reward.py:44-62  p = {min_cte, sparse_reward} */
+#define TC_T_CTE_LINEAR_REWARD 4            /* reward.py:64-84  p = {min_cte, max_reward, min_reward} */
+#define TC_T_LANELINE_CROSSING_TERMINATION 5 /* termination.py:4-22   layer_mask = lanelines */
+#define TC_T_CTE_TERMINATION 6              /* termination.py:24-48  p = {max_cte}, number_of_steps */
+#define TC_T_CRASH_TERMINATION 7            /* termination.py:50-70  p = {velocity threshold}, number_of_steps */
+
+typedef struct {
+  int32_t kind;            /* TC_T_* */
+  int32_t number_of_steps; /* consecutive-step terms */
+  uint32_t layer_mask;     /* bit l = lane-line layer l takes part */
+  int32_t reserved;
+  double p[4];
+  double per_layer[TC_MAX_LAYERS];
+} tc_term;
 
 typedef struct tc_map tc_map;
 typedef struct tc_env tc_env;
@@ -149,6 +170,15 @@ int tc_env_set_camera(tc_env* env, const tc_camera_params* cam);
  * K: device double [N][9], caller owned and read by every launch until replaced; (NULL, NULL) returns to the shared
  * camera of tc_env_create / tc_env_set_camera.  Resolution, max_range, thickness and format stay shared. */
 int tc_env_set_camera_per_env(tc_env* env, const double* E, const double* K);
+/* Installs n_terms (0..TC_MAX_TERMS) reward / termination terms; they apply to every tc_step enqueued afterwards
+ * (the call waits for earlier launches).  Each term starts from the reward / terminated value left by the one
+ * before it, the first from the base values of env.py:136-138 (0 / false under TC_F_WRAPPED, which the reference
+ * wrappers always set).  counters: device int32 [N][TC_MAX_TERMS], caller owned, zero-initialised: steps_true of
+ * the consecutive-step terms (termination.py:37,59), one per env and term slot; like the reference's attribute it
+ * is NOT cleared when an env is reset.  May be NULL when no such term is installed.  Envs re-spawned by
+ * TC_F_AUTORESET in a step skip the terms for that step (the reference's reset() does not pass through
+ * Wrapper.step): reward 0, terminated 0, counters untouched.  n_terms = 0 removes all terms. */
+int tc_env_set_terms(tc_env* env, const tc_term* terms, int32_t n_terms, int32_t* counters);
 /* bytes of one env's observation */
 int64_t tc_env_obs_bytes(const tc_env* env);
 /* dynamic LDS bytes one workgroup of the step kernel uses (for occupancy reporting) */

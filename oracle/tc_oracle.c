@@ -951,10 +951,76 @@ void orc_reset_batch(const orc_map* m, const orc_car* c, const orc_cam* cam, int
   }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Reward / termination wrappers (tinycarlo/wrapper/reward.py, termination.py, utils.py)
+ * ------------------------------------------------------------------------------------------- */
+double orc_linear_reward(double x, double max_x, double max_reward, double min_reward) {
+  double y = (-max_reward / max_x) * fabs(x) + max_reward; /* utils.py:33 */
+  if (max_reward > 0) return (min_reward > y) ? min_reward : y; /* utils.py:34-35, python max(y, min_reward) */
+  return (min_reward < y) ? min_reward : y;                     /* utils.py:36-37, python min(y, min_reward) */
+}
+
+void orc_apply_terms(const orc_term* terms, int n_terms, int C, double tw, orc_info* o, int32_t* counters) {
+  const double half = tw / 2;
+  double reward = o->reward;
+  int terminated = o->terminated;
+  for (int t = 0; t < n_terms; t++) {
+    const orc_term* T = &terms[t];
+    switch (T->kind) {
+      case ORC_T_LANELINE_SPARSE_REWARD: { /* reward.py:20-21; utils.py:15-19 sums into its own 0.0 first */
+        double local = 0.0;
+        for (int l = 0; l < C; l++)
+          if (((T->layer_mask >> l) & 1u) && o->dist[l] < half) local += T->per_layer[l];
+        reward = reward + local;
+      } break;
+      case ORC_T_LANELINE_LINEAR_REWARD: /* reward.py:40-41: one += per layer, in layer order */
+        for (int l = 0; l < C; l++) reward = reward + orc_linear_reward(o->dist[l], tw, T->per_layer[l], 0.0);
+        break;
+      case ORC_T_CTE_SPARSE_REWARD: { /* reward.py:60 */
+        double local = 0.0;
+        if (fabs(o->cte) <= T->p[0]) local += T->p[1];
+        reward = reward + local;
+      } break;
+      case ORC_T_CTE_LINEAR_REWARD: /* reward.py:83 */
+        reward = reward + orc_linear_reward(o->cte, T->p[0], T->p[1], T->p[2]);
+        break;
+      case ORC_T_LANELINE_CROSSING_TERMINATION: /* termination.py:19-21 */
+        for (int l = 0; l < C; l++)
+          if (((T->layer_mask >> l) & 1u) && o->dist[l] <= half) terminated = 1;
+        break;
+      case ORC_T_CTE_TERMINATION:   /* termination.py:39-47 */
+      case ORC_T_CRASH_TERMINATION: /* termination.py:61-69 */ {
+        int cond = T->kind == ORC_T_CTE_TERMINATION ? (fabs(o->cte) > T->p[0]) : (fabs(o->velocity) < T->p[0]);
+        if (cond) {
+          counters[t] += 1;
+          if (counters[t] >= T->number_of_steps) {
+            terminated = 1;
+            counters[t] = 0;
+          }
+        } else {
+          counters[t] = 0;
+        }
+      } break;
+      default: break;
+    }
+  }
+  o->reward = reward;
+  o->terminated = terminated;
+}
+
 void orc_step_batch(const orc_map* m, const orc_car* c, const orc_cam* cam, int N, orc_state* st,
                     const double* car_control, const int32_t* maneuver, uint32_t flags, orc_info* info, uint8_t* obs,
                     uint8_t* needs_reset, const int32_t* spawn_queue, int spawn_queue_len, int32_t* spawn_cursor,
                     int n_threads) {
+  orc_step_batch_terms(m, c, cam, N, st, car_control, maneuver, flags, info, obs, needs_reset, spawn_queue,
+                       spawn_queue_len, spawn_cursor, n_threads, NULL, 0, NULL);
+}
+
+void orc_step_batch_terms(const orc_map* m, const orc_car* c, const orc_cam* cam, int N, orc_state* st,
+                          const double* car_control, const int32_t* maneuver, uint32_t flags, orc_info* info,
+                          uint8_t* obs, uint8_t* needs_reset, const int32_t* spawn_queue, int spawn_queue_len,
+                          int32_t* spawn_cursor, int n_threads, const orc_term* terms, int n_terms,
+                          int32_t* counters) {
   int64_t ob = orc_obs_bytes(m, cam);
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(n_threads > 0 ? n_threads : 1) schedule(static)
@@ -981,6 +1047,8 @@ void orc_step_batch(const orc_map* m, const orc_car* c, const orc_cam* cam, int 
     o->status = status;
     o->truncated = trunc;
     orc_get_info(m, c, &st[i], flags, o);
+    if (n_terms > 0) 
+      orc_apply_terms(terms, n_terms, m->C, c->track_width, o, counters + (size_t)i * ORC_MAX_TERMS);
     if ((flags & ORC_F_AUTORESET) && needs_reset) needs_reset[i] = (o->terminated || o->truncated) ? 1 : 0;
   }
 }

@@ -77,6 +77,24 @@ typedef struct {
   int32_t terminated, truncated, status;
 } orc_info;
 
+/* tinycarlo/wrapper/reward.py + termination.py as an ordered list of terms (same layout and kind values as
+ * tc_term in include/tinycarlo_hip.h) */
+#define ORC_MAX_TERMS 8
+#define ORC_T_LANELINE_SPARSE_REWARD 1
+#define ORC_T_LANELINE_LINEAR_REWARD 2
+#define ORC_T_CTE_SPARSE_REWARD 3
+#define ORC_T_CTE_LINEAR_REWARD 4
+#define ORC_T_LANELINE_CROSSING_TERMINATION 5
+#define ORC_T_CTE_TERMINATION 6
+#define ORC_T_CRASH_TERMINATION 7
+typedef struct {
+  int32_t kind, number_of_steps;
+  uint32_t layer_mask;
+  int32_t reserved;
+  double p[4];
+  double per_layer[ORC_MAXC];
+} orc_term;
+
 void orc_set_math_mode(int mode);
 int orc_get_math_mode(void);
 
@@ -123,6 +141,19 @@ void orc_step_batch(const orc_map*, const orc_car*, const orc_cam*, int N, orc_s
 /* env.py:101-113 for a batch: reset + observation + empty info */
 void orc_reset_batch(const orc_map*, const orc_car*, const orc_cam*, int N, orc_state* st, const int32_t* spawn_node,
                      const uint8_t* mask, uint32_t flags, orc_info* info, uint8_t* obs, int n_threads);
+/* wrapper/utils.py:21-37 */
+double orc_linear_reward(double x, double max_x, double max_reward, double min_reward);
+/* One Wrapper.step() pass of the stacked wrappers over the info of one env (innermost term first): updates
+ * info->reward / info->terminated and the steps_true counters [ORC_MAX_TERMS] of this env. */
+void orc_apply_terms(const orc_term* terms, int n_terms, int n_layers, double track_width, orc_info* info,
+                     int32_t* counters);
+/* orc_step_batch followed by orc_apply_terms on every env that was stepped (re-spawned envs skip the terms, as
+ * the reference's reset() bypasses Wrapper.step); counters: [N][ORC_MAX_TERMS] */
+void orc_step_batch_terms(const orc_map*, const orc_car*, const orc_cam*, int N, orc_state* st,
+                          const double* car_control, const int32_t* maneuver, uint32_t flags, orc_info* info,
+                          uint8_t* obs, uint8_t* needs_reset, const int32_t* spawn_queue, int spawn_queue_len,
+                          int32_t* spawn_cursor, int n_threads, const orc_term* terms, int n_terms,
+                          int32_t* counters);
 int64_t orc_obs_bytes(const orc_map*, const orc_cam*);
 
 #ifdef __cplusplus

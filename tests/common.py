@@ -54,3 +54,42 @@ def map_of(fname):
 
 def cam_keys(d):
     return [k[4:] for k in d.files if k.startswith("seg_") and not k.endswith("_off")]
+
+
+def wrapper_cases():
+    """tests/golden/wrappers.json: the reference's wrapper classes run over recorded infos (gen_golden.py wrappers)"""
+    import json
+    with open(os.path.join(GOLDEN, "wrappers.json")) as f:
+        return json.load(f)
+
+
+def build_stack(env, spec, **extra):
+    """stacks this repo's wrappers as described by a wrappers.json "spec" ([[class name, kwargs]], innermost first)"""
+    import tinycarlo_amd.wrapper as W
+    for cls, kw in spec:
+        env = getattr(W, cls)(env, **kw, **extra)
+    return env
+
+
+def terms_of(spec, names):
+    """the same stack as tinycarlo_amd.terms.Term objects"""
+    from tinycarlo_amd import terms as T
+    out = []
+    for cls, kw in spec:
+        if cls == "LanelineSparseRewardWrapper":
+            out.append(T.laneline_sparse_reward(names, kw["sparse_rewards"]))
+        elif cls == "LanelineLinearRewardWrapper":
+            out.append(T.laneline_linear_reward(names, kw["max_rewards"]))
+        elif cls == "CTESparseRewardWrapper":
+            out.append(T.cte_sparse_reward(**kw))
+        elif cls == "CTELinearRewardWrapper":
+            out.append(T.cte_linear_reward(**kw))
+        elif cls == "LanelineCrossingTerminationWrapper":
+            out.append(T.laneline_crossing_termination(names, kw["lanelines"]))
+        elif cls == "CTETerminationWrapper":
+            out.append(T.cte_termination(**kw))
+        elif cls == "CrashTerminationWrapper":
+            out.append(T.crash_termination(kw["velcoity_threshold"], kw["number_of_steps"]))
+        else:
+            raise KeyError(cls)
+    return out

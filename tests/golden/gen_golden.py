@@ -455,6 +455,110 @@ def main_extra():
         print(name, "resets", len(out["reset_step"]), "trunc", int(out["truncated"].sum()), "term", int(out["terminated"].sum()))
 
 
+# ----------------------------------------------------------------------------- wrappers
+# Layer-indexed parameter tables (the stacks are written into wrappers.json as "spec", which is what the tests
+# build their own wrappers from; values picked so that every branch
+# fires on the recorded drives: distances are 0..0.3 m, track_width 0.027 m, cte 0..0.05 m).
+WRAP_LINEAR_A = [-1.0, -0.5, -1.0, 0.0, 0.25]
+WRAP_LINEAR_B = [0.5, 1.5, -0.125, 2.0, 0.0]
+
+
+def wrapper_stack(which, names):
+    """[(class name, kwargs)] innermost first."""
+    if which == "A":
+        return [("CTESparseRewardWrapper", dict(min_cte=0.01)),
+                ("CTELinearRewardWrapper", dict(min_cte=0.05, max_reward=2.0)),
+                ("LanelineLinearRewardWrapper", dict(max_rewards={n: WRAP_LINEAR_A[i % 5] for i, n in enumerate(names)})),
+                ("LanelineSparseRewardWrapper", dict(sparse_rewards={names[0]: -10.0})),
+                ("LanelineCrossingTerminationWrapper", dict(lanelines=names[0])),
+                ("CTETerminationWrapper", dict(max_cte=0.02, number_of_steps=3)),
+                ("CrashTerminationWrapper", dict(velcoity_threshold=0.005, number_of_steps=4))]
+    return [("CrashTerminationWrapper", dict(velcoity_threshold=0.05, number_of_steps=2)),
+            ("LanelineSparseRewardWrapper", dict(sparse_rewards={names[1]: 0.5, names[-1]: 2.0, "not_a_layer": 7.0})),
+            ("CTELinearRewardWrapper", dict(min_cte=0.03, max_reward=-1.0, min_reward=-0.25)),
+            ("LanelineCrossingTerminationWrapper", dict(lanelines=[names[-1], names[1]])),
+            ("CTETerminationWrapper", dict(max_cte=0.015, number_of_steps=1)),
+            ("LanelineLinearRewardWrapper", dict(max_rewards={n: WRAP_LINEAR_B[i % 5] for i, n in enumerate(names)})),
+            ("CTESparseRewardWrapper", dict(min_cte=0.02, sparse_reward=0.3))]
+
+
+def main_wrappers():
+    """The reference's wrapper classes (tinycarlo/wrapper/reward.py, termination.py) stacked on a replay env that
+    returns the info dicts of already recorded rollouts.  gymnasium is absent: `Wrapper` is stood in by the
+    minimal delegating class below (env / unwrapped / step), which is all the wrappers use."""
+    g = types.ModuleType("gymnasium")
+
+    class Env:
+        @property
+        def unwrapped(self):
+            return self
+
+    class Wrapper(Env):
+        def __init__(self, env):
+            self.env = env
+
+        @property
+        def unwrapped(self):
+            return self.env.unwrapped
+
+        def step(self, action):
+            return self.env.step(action)
+
+    g.Env, g.Wrapper = Env, Wrapper
+    sys.modules["gymnasium"] = g
+    import tinycarlo.wrapper.reward as rw
+    import tinycarlo.wrapper.termination as tm
+    from tinycarlo.wrapper.utils import linear_reward, sparse_reward
+
+    class Replay(Env):
+        def __init__(self, d, names, tw):
+            self.wrapped = False
+            self.car = type("CarStub", (), {"track_width": tw})()
+            self.d, self.names, self.t = d, names, 0
+
+        def step(self, action):
+            t = self.t
+            self.t += 1
+            info = {"cte": float(self.d["cte"][t]), "velocity": float(self.d["info_velocity"][t]),
+                    "laneline_distances": {n: float(self.d["dist"][t][i]) for i, n in enumerate(self.names)}}
+            return None, 0, False, False, info  # env.py:136-138 with wrapped == True
+
+    out = {"linear_A": WRAP_LINEAR_A, "linear_B": WRAP_LINEAR_B, "cases": [], "utils": []}
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        x, mx = float(rng.normal(0, 0.05)), float(rng.uniform(0.005, 0.1))
+        mr, mn = float(rng.choice([1.0, 2.0, -1.0, -0.5, 0.0])), float(rng.choice([0.0, -0.25, 0.5]))
+        out["utils"].append([x, mx, mr, mn, linear_reward(x, mx, mr, mn)])
+    assert sparse_reward({"a": True, "b": False, "c": True}, {"a": 1.0, "b": 5.0}) == 1.0
+    for fname in ["rollout_simple_layout_random_0.npz", "rollout_knuffingen_wild_2.npz",
+                  "rollout_formula_student_track_random_1.npz", "rollout_simple_layout_stanley_1.npz"]:
+        path = os.path.join(OUT, fname)
+        if not os.path.exists(path):
+            print("skip", fname)
+            continue
+        d = np.load(path)
+        mn = next(k for k in list(MAPS) + list(EXTRA_MAPS) if k in fname)
+        cfg, m, car, _ = load(mn)
+        names = m.get_laneline_names()
+        for which in ("A", "B"):
+            env = Replay(d, names, car.track_width)
+            for cls, kw in wrapper_stack(which, names):
+                env = getattr(rw, cls, None)(env, **kw) if hasattr(rw, cls) else getattr(tm, cls)(env, **kw)
+            assert env.unwrapped.wrapped is True
+            rewards, terms = [], []
+            for t in range(len(d["cte"])):
+                _, r, te, tr, _ = env.step(None)
+                rewards.append(float(r))
+                terms.append(bool(te))
+            out["cases"].append({"rollout": fname, "stack": which, "layers": names,
+                                 "track_width": car.track_width,
+                                 "spec": [[c, kw] for c, kw in wrapper_stack(which, names)],
+                                 "reward": rewards, "terminated": terms})
+            print(fname, which, "sum reward %.6f" % sum(rewards), "terminated", sum(terms), "of", len(terms))
+    with open(os.path.join(OUT, "wrappers.json"), "w") as f:
+        json.dump(out, f)
+
+
 def main():
     with open(os.path.join(OUT, "unit_vectors.json"), "w") as f:
         json.dump(unit_vectors(), f)
@@ -486,5 +590,7 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         main_extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == "wrappers":
+        main_wrappers()
     else:
         main()

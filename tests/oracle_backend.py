@@ -33,9 +33,19 @@ class OracleVecEnv(TinyCarloVecEnv):
                      "spawn_queue": torch.zeros((N, self.spawn_queue_len), dtype=i32),
                      "spawn_cursor": torch.zeros(N, dtype=i32)}
         self._lp_nodes = torch.as_tensor(np.asarray(self.map.lanepath.nodes, dtype=np.float64))
+        self.term_counters = torch.zeros((N, nat.MAX_TERMS), dtype=i32)
+        self.terms = []
         self.obs_bytes_per_env = self._o.obs_bytes
         self.lds_bytes = 0
         self._h = None
+
+    def set_terms(self, terms):
+        terms = list(terms)
+        if len(terms) > nat.MAX_TERMS:
+            raise ValueError(f"at most {nat.MAX_TERMS} fused terms")
+        self.term_counters.zero_()
+        self.terms = terms
+        self._o.terms = terms
 
     # -- tensors <-> oracle arrays
     def _push(self):
@@ -48,6 +58,7 @@ class OracleVecEnv(TinyCarloVecEnv):
         o.needs_reset[:] = self._aux["needs_reset"].numpy()
         o.spawn_queue = self._aux["spawn_queue"].numpy().copy()
         o.spawn_cursor[:] = self._aux["spawn_cursor"].numpy()
+        o.term_counters[:] = self.term_counters.numpy()
 
     def _pull(self, with_obs=True):
         o, C = self._o, self.n_classes
@@ -67,6 +78,7 @@ class OracleVecEnv(TinyCarloVecEnv):
             self.out["obs"].copy_(torch.from_numpy(o.obs.reshape((self.num_envs,) + self._obs_shape).copy()))
         self._aux["needs_reset"].copy_(torch.from_numpy(o.needs_reset.copy()))
         self._aux["spawn_cursor"].copy_(torch.from_numpy(o.spawn_cursor.copy()))
+        self.term_counters.copy_(torch.from_numpy(o.term_counters.copy()))
 
     def _oflags(self):
         f = self._flags()
@@ -91,6 +103,7 @@ class OracleVecEnv(TinyCarloVecEnv):
     def step_device(self, car_control, maneuver):
         if not self._was_reset:
             raise RuntimeError("step() before reset()")
+        self._note_fresh()
         self._push()
         no_obs = bool(self._oflags() & orc.F_NO_OBSERVATION)
         self._o.step(car_control.double().numpy(), maneuver.numpy(), flags=self._oflags(), with_obs=not no_obs)

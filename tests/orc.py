@@ -89,6 +89,12 @@ def lib():
         L.orc_polyline2.argtypes = [bp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, bp, C.c_int]
         L.orc_step_batch.argtypes = [C.c_void_p, C.POINTER(Car), C.POINTER(Cam), C.c_int, C.c_void_p, dp, ip,
                                      C.c_uint32, C.c_void_p, bp, bp, ip, C.c_int, ip, C.c_int]
+        L.orc_step_batch_terms.argtypes = [C.c_void_p, C.POINTER(Car), C.POINTER(Cam), C.c_int, C.c_void_p, dp, ip,
+                                           C.c_uint32, C.c_void_p, bp, bp, ip, C.c_int, ip, C.c_int,
+                                           C.c_void_p, C.c_int, ip]
+        L.orc_apply_terms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, ip]
+        L.orc_linear_reward.restype = C.c_double
+        L.orc_linear_reward.argtypes = [C.c_double] * 4
         L.orc_reset_batch.argtypes = [C.c_void_p, C.POINTER(Car), C.POINTER(Cam), C.c_int, C.c_void_p, ip, bp,
                                       C.c_uint32, C.c_void_p, bp, C.c_int]
         L.orc_obs_bytes.restype = C.c_int64
@@ -153,6 +159,24 @@ class OracleMap:
             pass
 
 
+MAX_TERMS = 8
+
+
+class Term(C.Structure):  # orc_term (same layout as tc_term)
+    _fields_ = [("kind", C.c_int32), ("number_of_steps", C.c_int32), ("layer_mask", C.c_uint32), ("reserved", C.c_int32),
+                ("p", C.c_double * 4), ("per_layer", C.c_double * 16)]
+
+
+def make_terms(terms):
+    """ctypes orc_term array from tinycarlo_amd.terms.Term objects"""
+    arr = (Term * max(len(terms), 1))()
+    for i, t in enumerate(terms):
+        arr[i].kind, arr[i].number_of_steps, arr[i].layer_mask = int(t.kind), int(t.number_of_steps), int(t.layer_mask)
+        arr[i].p[:] = [float(v) for v in t.p]
+        arr[i].per_layer[:] = [float(v) for v in t.per_layer]
+    return arr
+
+
 class Oracle:
     """A batch of N oracle envs (AoS state on the host)."""
 
@@ -169,6 +193,8 @@ class Oracle:
         self.needs_reset = np.zeros(n, dtype=np.uint8)
         self.spawn_cursor = np.zeros(n, dtype=np.int32)
         self.spawn_queue = np.zeros((n, 1), dtype=np.int32)
+        self.terms = []                                            # tinycarlo_amd.terms.Term, innermost first
+        self.term_counters = np.zeros((n, MAX_TERMS), dtype=np.int32)
 
     def set_camera(self, camera):
         fmt = self.cam.format
@@ -190,9 +216,11 @@ class Oracle:
         cc = np.ascontiguousarray(car_control, dtype=np.float64).reshape(self.n, 2)
         mn = np.ascontiguousarray(maneuver, dtype=np.int32).reshape(self.n)
         sq = np.ascontiguousarray(self.spawn_queue, dtype=np.int32)
-        lib().orc_step_batch(self.map.h, C.byref(self.car), C.byref(self.cam), self.n, self.state.ctypes.data, _dp(cc),
-                             _ip(mn), flags, self.info.ctypes.data, _bp(self.obs) if with_obs else None,
-                             _bp(self.needs_reset), _ip(sq), sq.shape[1], _ip(self.spawn_cursor), self.threads)
+        tarr = make_terms(self.terms)
+        lib().orc_step_batch_terms(self.map.h, C.byref(self.car), C.byref(self.cam), self.n, self.state.ctypes.data,
+                                   _dp(cc), _ip(mn), flags, self.info.ctypes.data, _bp(self.obs) if with_obs else None,
+                                   _bp(self.needs_reset), _ip(sq), sq.shape[1], _ip(self.spawn_cursor), self.threads,
+                                   C.cast(tarr, C.c_void_p), len(self.terms), _ip(self.term_counters))
 
     def segments(self, i: int = 0, cap: int = 4096):
         if getattr(self, "_segbuf", None) is None or len(self._segbuf[0]) < cap:

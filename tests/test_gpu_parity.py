@@ -434,3 +434,98 @@ def test_abi_error_paths_on_device():
     assert (st[:3] & nat.S_BAD_SPAWN).all() and not (st[3:] & nat.S_BAD_SPAWN).any()
     assert int(env.state["lp_len"].min()) == 1 and int(env.state["local_path"][:, 0].min()) >= 0
     env.close()
+
+
+# ------------------------------------------------------------------ fused reward / termination terms
+def _wrapper_spec(which, mp):
+    from common import wrapper_cases
+    return next(c["spec"] for c in wrapper_cases()["cases"] if c["stack"] == which and mp in c["rollout"])
+
+
+@pytest.mark.parametrize("which", ["A", "B"])
+@pytest.mark.parametrize("mp,rk,N,fuse_env", [("simple_layout", "r64", 512, "1"), ("knuffingen", "r64", 192, "1"),
+                                              ("simple_layout", "r64", 96, "0")])
+def test_fused_terms_vs_oracle(mp, rk, N, fuse_env, which, monkeypatch):
+    """The wrapper stacks of tests/golden/wrappers.json evaluated in the step kernel's epilogue (tc_env_set_terms)
+    vs the oracle's orc_apply_terms (itself pinned to the reference's wrapper classes, tests/test_wrappers.py):
+    reward bits, terminated, the consecutive-step counters and the autoreset decisions identical for a whole
+    rollout.  Both launch modes (TC_FUSE) and the K = 13 two-launch map."""
+    from common import terms_of
+    monkeypatch.setenv("TC_FUSE", fuse_env)
+    env = make_env(mp, rk, "classes", N, autoreset=True, spawn_queue_len=8)
+    env.wrapped = True
+    terms = terms_of(_wrapper_spec(which, mp), env.layer_names)
+    env.set_terms(terms)
+    o = make_oracle(env)
+    o.terms = terms
+    C = env.n_classes
+    env.reset(seed=77)
+    o.spawn_queue = env._aux["spawn_queue"].cpu().numpy()
+    o.spawn_cursor[:] = 0
+    o.needs_reset[:] = 0
+    o.reset(env._keep[0].cpu().numpy(), flags=orc.F_WRAPPED)
+    rng = np.random.default_rng(9)
+    fired = resets = 0
+    for t in range(80):
+        man = rng.integers(0, 4, N).astype(np.int32)
+        # slow-ish and sometimes stopped cars so that the crash term (|velocity| < threshold) takes part
+        cc = np.stack([rng.choice([0.0, 0.02, 0.6, 1.0], N), rng.uniform(-1.0, 1.0, N)], axis=1).astype(np.float32)
+        resets += int(o.needs_reset.sum())
+        o.step(cc.astype(np.float64), man, flags=orc.F_AUTORESET | orc.F_WRAPPED)
+        env.step({"car_control": cc, "maneuver": man})
+        assert_same(env, o, C, check_obs=(t % 16 == 15), label=f"terms {mp}/{which} step {t}")
+        assert np.array_equal(env.term_counters.cpu().numpy(), o.term_counters), t
+        assert np.array_equal(env._aux["needs_reset"].cpu().numpy(), o.needs_reset), t
+        fired += int(o.info["terminated"].sum())
+    assert fired > N // 8 and resets > N // 8
+    assert float(env.out["reward"].abs().max()) > 0
+    env.close()
+
+
+def test_fused_wrappers_equal_torch_side_wrappers_on_gpu():
+    """the shipped wrapper classes on the HIP env: fused (default) and torch-side (fuse=False) give the same numbers"""
+    from common import build_stack
+    spec = _wrapper_spec("A", "simple_layout")
+    N = 256
+    pair = []
+    for fuse in (None, False):
+        e = make_env("simple_layout", "r64", "classes", N, autoreset=True, spawn_queue_len=8)
+        e.no_observation = True
+        w = build_stack(e, spec, fuse=fuse)
+        w.reset(seed=3)
+        pair.append((e, w))
+    (ef, wf), (et, wt) = pair
+    assert len(ef.terms) == 7 and wf.fused and not wt.fused
+    g = torch.Generator().manual_seed(1)
+    tot = 0
+    for t in range(64):
+        cc = torch.stack([torch.rand(N, generator=g) * 0.7 + 0.3, torch.rand(N, generator=g) * 2 - 1], dim=1).numpy().astype(np.float32)
+        man = np.full(N, (t // 8) % 4, dtype=np.int32)
+        _, r1, te1, tr1, _ = wf.step({"car_control": cc, "maneuver": man})
+        _, r2, te2, tr2, _ = wt.step({"car_control": cc, "maneuver": man})
+        assert torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), t
+        tot += int(te1.sum())
+    assert tot > 10
+    ef.close()
+    et.close()
+
+
+def test_set_terms_error_paths():
+    import ctypes as C
+    from tinycarlo_amd import _native as nat
+    from tinycarlo_amd import terms as T
+    env = make_env("simple_layout", "r64", "classes", 4)
+    L = nat.lib()
+    cnt = env.term_counters.data_ptr()
+    bad_kind = nat.make_terms([T.Term(99)])
+    assert L.tc_env_set_terms(env._h, bad_kind, 1, cnt) == -1
+    bad_mask = nat.make_terms([T.Term(T.LANELINE_CROSSING_TERMINATION, layer_mask=1 << 9)])  # the map has 5 layers
+    assert L.tc_env_set_terms(env._h, bad_mask, 1, cnt) == -1
+    needs_cnt = nat.make_terms([T.cte_termination(0.1, 2)])
+    assert L.tc_env_set_terms(env._h, needs_cnt, 1, None) == -1
+    assert L.tc_env_set_terms(env._h, needs_cnt, 9, cnt) == -1
+    assert L.tc_env_set_terms(env._h, None, 1, cnt) == -1
+    assert b"tc_env_set_terms" in L.tc_last_error()
+    assert L.tc_env_set_terms(env._h, needs_cnt, 1, cnt) == 0
+    assert L.tc_env_set_terms(env._h, None, 0, None) == 0   # removes the terms
+    env.close()

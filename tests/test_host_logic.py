@@ -203,7 +203,8 @@ def _drive(env, n, batched):
             a = {"car_control": np.tile([[0.7, 0.3 * math.sin(t / 5)]], (N, 1)), "maneuver": np.full(N, t // 20 % 4, dtype=np.int32)}
         else:
             a = {"car_control": [0.7, 0.3 * math.sin(t / 5)], "maneuver": t // 20 % 4}
-        out.append(env.step(a))
+        # the batched env returns its live output tensors (overwritten by the next step): keep copies
+        out.append(tuple(x.clone() if isinstance(x, torch.Tensor) else x for x in env.step(a)))
     return out
 
 

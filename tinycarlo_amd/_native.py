@@ -17,14 +17,15 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtinycarlo_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+MAX_TERMS, MAX_LAYERS = 8, 16
 FMT_RGB, FMT_CLASSES = 0, 1
 F32, F64 = 0, 1
 F_NO_OBSERVATION, F_WRAPPED, F_AUTORESET = 1, 2, 4
 S_UTURN_NO_EDGE, S_PICK_EMPTY, S_BAD_SPAWN, S_NOT_RESET = 1, 2, 4, 8
 
 EXPORTS = ["tc_abi_version", "tc_last_error", "tc_map_create", "tc_map_destroy", "tc_env_create", "tc_env_destroy",
-           "tc_env_bind", "tc_env_set_camera", "tc_env_set_camera_per_env", "tc_env_obs_bytes", "tc_env_lds_bytes", "tc_env_profile",
+           "tc_env_bind", "tc_env_set_camera", "tc_env_set_camera_per_env", "tc_env_set_terms", "tc_env_obs_bytes", "tc_env_lds_bytes", "tc_env_profile",
            "tc_env_profile_read", "tc_reset", "tc_step", "tc_render", "tc_render_segments"]
 
 _dp, _ip, _bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
@@ -53,6 +54,21 @@ class Buffers(C.Structure):
                  "last_maneuver", "cte", "heading_error", "reward", "terminated", "truncated", "status",
                  "laneline_distances", "nearest_edge", "obs", "needs_reset", "spawn_queue", "spawn_cursor")] + \
                [("spawn_queue_len", C.c_int32)]
+
+
+class TermC(C.Structure):  # tc_term
+    _fields_ = [("kind", C.c_int32), ("number_of_steps", C.c_int32), ("layer_mask", C.c_uint32), ("reserved", C.c_int32),
+                ("p", C.c_double * 4), ("per_layer", C.c_double * MAX_LAYERS)]
+
+
+def make_terms(terms):
+    """ctypes array of tc_term from tinycarlo_amd.terms.Term objects"""
+    arr = (TermC * max(len(terms), 1))()
+    for i, t in enumerate(terms):
+        arr[i].kind, arr[i].number_of_steps, arr[i].layer_mask = int(t.kind), int(t.number_of_steps), int(t.layer_mask)
+        arr[i].p[:] = [float(v) for v in t.p]
+        arr[i].per_layer[:] = [float(v) for v in t.per_layer]
+    return arr
 
 
 class NativeError(RuntimeError):
@@ -90,6 +106,7 @@ def lib():
     L.tc_env_bind.argtypes = [C.c_void_p, C.POINTER(Buffers)]
     L.tc_env_set_camera.argtypes = [C.c_void_p, C.POINTER(CameraParamsC)]
     L.tc_env_set_camera_per_env.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tc_env_set_terms.argtypes = [C.c_void_p, C.POINTER(TermC), C.c_int32, C.c_void_p]
     L.tc_env_obs_bytes.restype = C.c_int64
     L.tc_env_obs_bytes.argtypes = [C.c_void_p]
     L.tc_env_lds_bytes.restype = C.c_int64

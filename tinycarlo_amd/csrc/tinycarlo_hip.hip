@@ -66,7 +66,70 @@ struct KArgs {
   int* seg_g;  // [N][seg_cap][5] draw list of the current frame (library owned)
   int* seg_n;  // [N]
   int seg_cap;
+  const tc_term* terms;  // device table [TC_MAX_TERMS] (library owned); reward / termination wrappers
+  int n_terms;
+  int* term_counters;    // [N][TC_MAX_TERMS] (caller owned)
 };
+
+// ---------------------------------------------------------------------------------------------
+// Reward / termination wrappers (tinycarlo/wrapper/*.py) as an epilogue of the step.  Every lane runs the same
+// scalar code; dist_l is lane l's laneline distance (lanes >= C hold 0) and is broadcast layer by layer so that
+// the additions happen in the dict order of info["laneline_distances"] (env.py:85, reward.py:20,40).
+__device__ inline double d_linear_reward(double x, double max_x, double max_reward, double min_reward) {
+  double y = (-max_reward / max_x) * tc_fabs(x) + max_reward;  // utils.py:33
+  if (max_reward > 0) return (min_reward > y) ? min_reward : y;  // python max(y, min_reward)
+  return (min_reward < y) ? min_reward : y;                      // python min(y, min_reward)
+}
+
+// (scalars by value: a reference to the kernel-argument struct would force a copy of it into scratch)
+__device__ __forceinline__ void d_apply_terms(const tc_term* terms, int n_terms, int* counters, double tw, int env,
+                                              int tid, int C, double cte, double vel, double dist_l, double& reward,
+                                              int& terminated) {
+  const double half = tw / 2;
+  for (int t = 0; t < n_terms; t++) {
+    const tc_term* T = terms + t;
+    const int kind = T->kind;
+    const unsigned mask = T->layer_mask;
+    if (kind == TC_T_LANELINE_SPARSE_REWARD) {  // reward.py:20-21, utils.py:15-19
+      double local = 0.0;
+      for (int l = 0; l < C; l++) {
+        const double d = __shfl(dist_l, l);
+        if (((mask >> l) & 1u) && d < half) local += T->per_layer[l];
+      }
+      reward = reward + local;
+    } else if (kind == TC_T_LANELINE_LINEAR_REWARD) {  // reward.py:40-41
+      for (int l = 0; l < C; l++) {
+        const double d = __shfl(dist_l, l);
+        reward = reward + d_linear_reward(d, tw, T->per_layer[l], 0.0);
+      }
+    } else if (kind == TC_T_CTE_SPARSE_REWARD) {  // reward.py:60
+      double local = 0.0;
+      if (tc_fabs(cte) <= T->p[0]) local += T->p[1];
+      reward = reward + local;
+    } else if (kind == TC_T_CTE_LINEAR_REWARD) {  // reward.py:83
+      reward = reward + d_linear_reward(cte, T->p[0], T->p[1], T->p[2]);
+    } else if (kind == TC_T_LANELINE_CROSSING_TERMINATION) {  // termination.py:19-21
+      for (int l = 0; l < C; l++) {
+        const double d = __shfl(dist_l, l);
+        if (((mask >> l) & 1u) && d <= half) terminated = 1;
+      }
+    } else if (kind == TC_T_CTE_TERMINATION || kind == TC_T_CRASH_TERMINATION) {  // termination.py:39-47,61-69
+      const bool cond = kind == TC_T_CTE_TERMINATION ? (tc_fabs(cte) > T->p[0]) : (tc_fabs(vel) < T->p[0]);
+      int* cp = counters + (size_t)env * TC_MAX_TERMS + t;
+      int c = *cp;
+      if (cond) {
+        c += 1;
+        if (c >= T->number_of_steps) {
+          terminated = 1;
+          c = 0;
+        }
+      } else {
+        c = 0;
+      }
+      if (tid == 0) *cp = c;
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Per-lane register cache of the map: lane `tid` keeps nodes / edges (w*K + k)*64 + tid, k < K, of window w.
@@ -204,8 +267,10 @@ __device__ inline int wave_incl_scan(int v) {
 #define TC_MIN_WAVES 4
 #endif
 // Stage 1 (simulate) for one env by one wavefront.  Returns false when nothing is to be rasterised for this env.
+// always inlined: out of line, `a` would be a pointer into private memory and the whole kernel-argument struct
+// (~1 KB) would be copied to scratch by every lane (the inliner's cost threshold is close: measured 47.9 k vs 47.6 k)
 template <int K>
-__device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, int mode, const void* car_control, int cdtype,
+__device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, int env, int mode, const void* car_control, int cdtype,
                                 const int* maneuver, const int* spawn_nodes, const unsigned char* mask,
                                 unsigned int flags) {
   const int tid = threadIdx.x;
@@ -304,6 +369,7 @@ __device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, in
       reward = (0 > r) ? 0 : r;
       terminated = cte > (a.car.track_width * 10);
     }
+    const bool late = a.n_terms > 0;  // reward / terminated depend on phase B: written after it
     if (tid == 0) {
       b.x[env] = s.x;
       b.y[env] = s.y;
@@ -317,11 +383,13 @@ __device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, in
       b.last_maneuver[env] = s.last_maneuver;
       b.cte[env] = cte;
       b.heading_error[env] = he;
-      b.reward[env] = reward;
-      b.terminated[env] = (unsigned char)terminated;
       b.truncated[env] = (unsigned char)trunc;
       b.status[env] = status;
-      if (b.needs_reset) b.needs_reset[env] = (flags & TC_F_AUTORESET) ? (unsigned char)(terminated || trunc) : 0;
+      if (!late) {
+        b.reward[env] = reward;
+        b.terminated[env] = (unsigned char)terminated;
+        if (b.needs_reset) b.needs_reset[env] = (flags & TC_F_AUTORESET) ? (unsigned char)(terminated || trunc) : 0;
+      }
     }
     if (tid < 8) {  // register-resident select (a runtime-indexed s.lp[tid] would live in scratch)
       int v = s.lp[0];
@@ -332,6 +400,7 @@ __device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, in
 
     // ---- phase B: lane-line distances (car.py:55-64)
     const int C = m.C;
+    double dist_l = 0;  // lane l < C: distance to lane-line layer l (0 while the info is empty, car.py:47-51)
     if (have_info && !(flags & DBG_SKIP_DIST)) {
       for (int w = 0; w < nwin_n; w++) {
         if (!single) cache_nodes(mc, m, w);
@@ -366,7 +435,6 @@ __device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, in
       }
       if (tid < C) {
         const int l = tid;
-        double dist_l = 0;
         if (my_e >= 0) {
           const int ge = m.edge_off[l] + my_e;
           int2 ed = m.edges_g[ge];
@@ -386,6 +454,17 @@ __device__ inline bool sim_body(const KArgs& a, unsigned char* smem, int env, in
     } else if (tid < C) {
       b.laneline_distances[(size_t)env * C + tid] = 0;
       b.nearest_edge[(size_t)env * C + tid] = -1;
+    }
+    if (late) {
+      // a re-spawned env did not go through Wrapper.step (the reference's reset() bypasses the wrappers)
+      if (!fresh)
+        d_apply_terms(a.terms, a.n_terms, a.term_counters, a.car.track_width, env, tid, C, cte,
+                      have_info ? s.velocity : 0.0, dist_l, reward, terminated);
+      if (tid == 0) {
+        b.reward[env] = reward;
+        b.terminated[env] = (unsigned char)terminated;
+        if (b.needs_reset) b.needs_reset[env] = (flags & TC_F_AUTORESET) ? (unsigned char)(terminated || trunc) : 0;
+      }
     }
   }
 
@@ -529,7 +608,7 @@ struct RArgs {
 #define TC_RASTER_WAVES 4
 #endif
 template <bool THICK, int FMT>
-__device__ inline void raster_body(const RArgs& a, unsigned char* smem, int env) {
+__device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem, int env) {
   const int tid = threadIdx.x;
   const RCam& cam = a.cam;
   unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
@@ -1242,6 +1321,7 @@ extern "C" int tc_env_destroy(tc_env* e) {
   }
   if (e && e->k.seg_g) (void)hipFree(e->k.seg_g);
   if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
+  if (e && e->k.terms) (void)hipFree((void*)e->k.terms);
   delete e;
   return TC_OK;
 }
@@ -1270,6 +1350,40 @@ extern "C" int tc_env_set_camera_per_env(tc_env* e, const double* E, const doubl
   if (!e || ((E == nullptr) != (K == nullptr))) return TC_E_INVALID;
   e->k.cam_E = E;
   e->k.cam_K = K;
+  return TC_OK;
+}
+
+extern "C" int tc_env_set_terms(tc_env* e, const tc_term* terms, int32_t n_terms, int32_t* counters) {
+  if (!e || n_terms < 0 || n_terms > TC_MAX_TERMS || (n_terms > 0 && !terms)) {
+    set_err("tc_env_set_terms: n_terms must be 0..TC_MAX_TERMS with a term array");
+    return TC_E_INVALID;
+  }
+  const int C = e->k.m.C;
+  const uint32_t all = C >= 32 ? 0xffffffffu : ((1u << C) - 1u);
+  for (int t = 0; t < n_terms; t++) {
+    const tc_term& T = terms[t];
+    if (T.kind < TC_T_LANELINE_SPARSE_REWARD || T.kind > TC_T_CRASH_TERMINATION) {
+      set_err("tc_env_set_terms: unknown term kind");
+      return TC_E_INVALID;
+    }
+    if (T.layer_mask & ~all) {
+      set_err("tc_env_set_terms: layer_mask names a layer the map does not have");
+      return TC_E_INVALID;
+    }
+    if ((T.kind == TC_T_CTE_TERMINATION || T.kind == TC_T_CRASH_TERMINATION) && !counters) {
+      set_err("tc_env_set_terms: consecutive-step terms need the counters buffer");
+      return TC_E_INVALID;
+    }
+  }
+  HIP_TRY(hipDeviceSynchronize());  // launches in flight still read the old table
+  if (!e->k.terms) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, sizeof(tc_term) * TC_MAX_TERMS));
+    e->k.terms = (const tc_term*)p;
+  }
+  if (n_terms > 0) HIP_TRY(hipMemcpy((void*)e->k.terms, terms, sizeof(tc_term) * n_terms, hipMemcpyHostToDevice));
+  e->k.n_terms = n_terms;
+  e->k.term_counters = counters;
   return TC_OK;
 }
 

@@ -28,6 +28,7 @@ from . import gym
 from .camera import Camera
 from .config import CarParams, load_config
 from .map import Map
+from .terms import Term
 
 
 def _default_device() -> torch.device:
@@ -97,6 +98,10 @@ class TinyCarloVecEnv(gym.Env):
         self._setup_device()
         self._rngs: List[Optional[np.random.Generator]] = [None] * self.num_envs
         self._was_reset = False
+        # torch-side (non-fused) wrappers ask for the mask of envs an autoreset step re-spawned: those did not go
+        # through Wrapper.step in the reference's flow (reset() bypasses the wrappers)
+        self.track_fresh = False
+        self.last_fresh: Optional[torch.Tensor] = None
 
     def _setup_device(self) -> None:
         """Creates the native handles and the device tensors the HIP library works on (no CPU path)."""
@@ -131,6 +136,9 @@ class TinyCarloVecEnv(gym.Env):
             self._aux: Dict[str, torch.Tensor] = {
                 "needs_reset": torch.zeros(N, **u8), "spawn_queue": torch.zeros((N, self.spawn_queue_len), **i32),
                 "spawn_cursor": torch.zeros(N, **i32)}
+            # steps_true of the consecutive-step termination terms (termination.py:37,59), one per env and slot
+            self.term_counters = torch.zeros((N, nat.MAX_TERMS), **i32)
+            self.terms: List[Term] = []
             self._lp_nodes = torch.as_tensor(np.asarray(self.map.lanepath.nodes, dtype=np.float64), device=dev)
             b = nat.Buffers()
             for k, t in {**self.state, **self.out, **self._aux}.items():
@@ -197,6 +205,25 @@ class TinyCarloVecEnv(gym.Env):
         Kt = torch.as_tensor(K, dtype=torch.float64).to(self.device).contiguous()
         self._env_cams = (Et, Kt)  # keep the device copies alive: the library reads them on every launch
         nat.check(nat.lib().tc_env_set_camera_per_env(self._h, Et.data_ptr(), Kt.data_ptr()), "tc_env_set_camera_per_env")
+
+    # ------------------------------------------------------------------ fused reward / termination wrappers
+    def set_terms(self, terms: Sequence[Term]) -> None:
+        """Installs the wrapper stack `terms` (innermost first) into the step kernel (tc_env_set_terms); the
+        counters of the consecutive-step terms are cleared.  An empty list removes all terms."""
+        terms = list(terms)
+        if len(terms) > nat.MAX_TERMS:
+            raise ValueError(f"at most {nat.MAX_TERMS} fused terms")
+        arr = nat.make_terms(terms)
+        with torch.cuda.device(self.device):
+            self.term_counters.zero_()
+            nat.check(nat.lib().tc_env_set_terms(self._h, arr, len(terms), self.term_counters.data_ptr()),
+                      "tc_env_set_terms")
+        self.terms = terms
+
+    def add_term(self, term: Term) -> int:
+        """Appends one term (the next wrapper of the stack); returns its slot in `term_counters`."""
+        self.set_terms(self.terms + [term])
+        return len(self.terms) - 1
 
     def _to_dev(self, key: str, a, dtype: torch.dtype, shape: Tuple[int, ...]) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
@@ -275,11 +302,23 @@ class TinyCarloVecEnv(gym.Env):
         """The bare hot path: one launch, nothing returned (results are in self.out / self.state)."""
         if not self._was_reset:
             raise RuntimeError("step() before reset()")
+        self._note_fresh()
         dt = nat.F64 if car_control.dtype == torch.float64 else nat.F32
         with torch.cuda.device(self.device):
             nat.check(nat.lib().tc_step(self._h, car_control.data_ptr(), dt, maneuver.data_ptr(), self._flags(),
                                         self._stream()), "tc_step")
         self._keep = (car_control, maneuver)
+
+    def request_reset(self, mask: torch.Tensor) -> None:
+        """Marks envs for re-spawning at the start of the next autoreset step, in addition to the ones the engine
+        flagged itself (terminated | truncated).  Torch-side termination wrappers call this with their result;
+        fused terms do it inside the kernel."""
+        if self.autoreset:
+            self._aux["needs_reset"] |= mask.to(torch.uint8)
+
+    def _note_fresh(self) -> None:
+        """before a step: the envs this step is going to re-spawn (only kept when a torch-side wrapper asked)"""
+        self.last_fresh = self._aux["needs_reset"].bool() if (self.track_fresh and self.autoreset) else None
 
     def profile(self, every: int = 1) -> None:
         """Record HIP events around the two kernels of every `every`-th step (ring of the last 64 samples); 0 = off."""
