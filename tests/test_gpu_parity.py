@@ -529,3 +529,52 @@ def test_set_terms_error_paths():
     assert L.tc_env_set_terms(env._h, needs_cnt, 1, cnt) == 0
     assert L.tc_env_set_terms(env._h, None, 0, None) == 0   # removes the terms
     env.close()
+
+
+@pytest.mark.parametrize("fuse_env", ["1", "0"])
+def test_mid_sized_map_k8_variant(tmp_path, fuse_env, monkeypatch):
+    """Maps with 321..512 lane-line nodes / edges run the K = 8 register-cache variant (tc_step_kernel<8>, or
+    tc_env_kernel<8> with TC_FUSE=0), which no bundled map selects: simple_layout plus shifted copies of four of its
+    layers (9 layers, 371 nodes, 336 edges)."""
+    import json
+    import os
+    from tinycarlo_amd.vec_env import TinyCarloVecEnv
+    monkeypatch.setenv("TC_FUSE", fuse_env)
+    cfg, path = load_cfg("simple_layout")
+    cfg = copy.deepcopy(cfg)
+    src = os.path.join(os.path.dirname(path), cfg["map"]["json_path"])
+    with open(src) as f:
+        mj = json.load(f)
+    lanes = dict(mj["lanelines"])
+    for name in ("dashed", "solid", "hold", "area"):
+        layer = mj["lanelines"][name]
+        lanes[f"{name}_b"] = {"layer_color": [(c + 90) % 256 for c in layer["layer_color"]],
+                              "nodes": [[n[0] + 23, n[1] + 17] for n in layer["nodes"]], "edges": layer["edges"]}
+    mj["lanelines"] = lanes
+    tn = sum(len(l["nodes"]) for l in lanes.values())
+    te = sum(len(l["edges"]) for l in lanes.values())
+    assert 320 < max(tn, te) <= 512, (tn, te)
+    mp = tmp_path / "mid.json"
+    mp.write_text(json.dumps(mj))
+    cfg["map"]["json_path"] = str(mp)
+    cfg["camera"]["resolution"] = [64, 64]
+    for fmt, th in (("classes", 2), ("rgb", 1)):
+        cfg["sim"]["observation_space_format"] = fmt
+        cfg["camera"]["line_thickness"] = th
+        N = 192
+        env = TinyCarloVecEnv(cfg, num_envs=N, device="cuda:0", autoreset=True, spawn_queue_len=4)
+        assert env.n_classes == 9
+        o = make_oracle(env)
+        env.reset(seed=5)
+        o.spawn_queue = env._aux["spawn_queue"].cpu().numpy()
+        o.reset(env._keep[0].cpu().numpy())
+        assert_same(env, o, env.n_classes, label="mid reset")
+        rng = np.random.default_rng(2)
+        for t in range(24):
+            cc = np.stack([rng.uniform(-0.2, 1.1, N), rng.uniform(-1.1, 1.1, N)], axis=1)
+            man = rng.integers(0, 4, N).astype(np.int32)
+            o.step(cc, man, flags=orc.F_AUTORESET)
+            env.step({"car_control": cc, "maneuver": man})
+            assert_same(env, o, env.n_classes, check_obs=(t % 4 == 3), label=f"mid map {fmt} fuse={fuse_env} step {t}")
+        assert int(env.out["obs"].max()) > 0
+        env.close()
