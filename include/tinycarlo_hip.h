@@ -64,6 +64,10 @@ extern "C" {
                                   start of the step (their action is ignored, reward 0, info empty) and the
                                   flag is set again from terminated|truncated at the end of the step */
 
+#define TC_F_DEVICE_SPAWN 8u    /* with TC_F_AUTORESET: re-spawn nodes are drawn on the device from the table of
+                                  tc_env_set_spawn_table (counter-based, tinycarlo_amd/csrc/tc_rng.h) instead of
+                                  being read from spawn_queue; spawn_cursor[i] counts env i's re-spawns */
+
 /* per-env status bits (tc_buffers.status), situations where the reference raises a Python exception */
 #define TC_S_UTURN_NO_EDGE 1 /* U-turn found no lanepath edge within +-30 deg (TypeError at car.py:143): truncated */
 #define TC_S_PICK_EMPTY 2    /* neighbour list made only of self-loops (ValueError at layer.py:123): truncated */
@@ -179,6 +183,12 @@ int tc_env_set_camera_per_env(tc_env* env, const double* E, const double* K);
  * TC_F_AUTORESET in a step skip the terms for that step (the reference's reset() does not pass through
  * Wrapper.step): reward 0, terminated 0, counters untouched.  n_terms = 0 removes all terms. */
 int tc_env_set_terms(tc_env* env, const tc_term* terms, int32_t n_terms, int32_t* counters);
+/* Device-side spawn sampling (TC_F_DEVICE_SPAWN).  nodes: HOST array of n > 0 lanepath node ids, copied by the call:
+ * the candidates of Map.sample_spawn (map.py:61: spawn_points, or 0..len(nodes)-2) that have an out-edge, duplicates
+ * kept -- a uniform draw from it is distributed like the reference's draw-again-on-sinks loop (map.py:62-64).
+ * Re-spawn number k of env i uses SplitMix64 output (i << 32 | k) of the stream `seed`.  Not seed-compatible with
+ * the reference's numpy generator; the host-drawn spawn_queue remains the seed-parity mode.  n = 0 removes the table. */
+int tc_env_set_spawn_table(tc_env* env, const int32_t* nodes, int32_t n, uint64_t seed);
 /* bytes of one env's observation */
 int64_t tc_env_obs_bytes(const tc_env* env);
 /* dynamic LDS bytes one workgroup of the step kernel uses (for occupancy reporting) */

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include "../tinycarlo_amd/csrc/tc_trig.h" /* ORC_MATH_PORTABLE only */
+#include "../tinycarlo_amd/csrc/tc_rng.h"  /* ORC_F_DEVICE_SPAWN only (no reference counterpart) */
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -1021,6 +1022,27 @@ void orc_step_batch_terms(const orc_map* m, const orc_car* c, const orc_cam* cam
                           uint8_t* obs, uint8_t* needs_reset, const int32_t* spawn_queue, int spawn_queue_len,
                           int32_t* spawn_cursor, int n_threads, const orc_term* terms, int n_terms,
                           int32_t* counters) {
+  orc_step_ext ext;
+  memset(&ext, 0, sizeof(ext));
+  ext.terms = terms;
+  ext.n_terms = n_terms;
+  ext.counters = counters;
+  orc_step_batch_ext(m, c, cam, N, st, car_control, maneuver, flags, info, obs, needs_reset, spawn_queue,
+                     spawn_queue_len, spawn_cursor, n_threads, &ext);
+}
+
+uint64_t orc_splitmix64_at(uint64_t seed, uint64_t n) { return tc_splitmix64_at(seed, n); }
+uint32_t orc_spawn_index(uint64_t seed, uint32_t env, uint32_t cursor, uint32_t count) {
+  return tc_spawn_index(seed, env, cursor, count);
+}
+
+void orc_step_batch_ext(const orc_map* m, const orc_car* c, const orc_cam* cam, int N, orc_state* st,
+                        const double* car_control, const int32_t* maneuver, uint32_t flags, orc_info* info,
+                        uint8_t* obs, uint8_t* needs_reset, const int32_t* spawn_queue, int spawn_queue_len,
+                        int32_t* spawn_cursor, int n_threads, const orc_step_ext* ext) {
+  const orc_term* terms = ext ? ext->terms : NULL;
+  const int n_terms = ext ? ext->n_terms : 0;
+  int32_t* counters = ext ? ext->counters : NULL;
   int64_t ob = orc_obs_bytes(m, cam);
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(n_threads > 0 ? n_threads : 1) schedule(static)
@@ -1029,7 +1051,12 @@ void orc_step_batch_terms(const orc_map* m, const orc_car* c, const orc_cam* cam
     orc_info* o = &info[i];
     uint8_t* oi = obs ? obs + (size_t)i * ob : NULL;
     if ((flags & ORC_F_AUTORESET) && needs_reset && needs_reset[i]) {
-      int node = spawn_queue[(size_t)i * spawn_queue_len + (spawn_cursor[i] % spawn_queue_len)];
+      int node;
+      if ((flags & ORC_F_DEVICE_SPAWN) && ext && ext->spawn_n > 0)
+        node = ext->spawn_table[tc_spawn_index(ext->spawn_seed, (uint32_t)i, (uint32_t)spawn_cursor[i],
+                                               (uint32_t)ext->spawn_n)];
+      else
+        node = spawn_queue[(size_t)i * spawn_queue_len + (spawn_cursor[i] % spawn_queue_len)];
       spawn_cursor[i]++;
       orc_reset(m, c, &st[i], node);
       memset(o, 0, sizeof(*o));

@@ -39,6 +39,7 @@ extern "C" {
 #define ORC_F_NO_OBSERVATION 1u /* env.py:60,78-81 */
 #define ORC_F_WRAPPED 2u        /* env.py:56,137-138: default reward/termination disabled */
 #define ORC_F_AUTORESET 4u      /* batched extension: reset finished envs at the start of the next step */
+#define ORC_F_DEVICE_SPAWN 8u   /* with AUTORESET: spawn node from the counter-based table draw (csrc/tc_rng.h) */
 
 /* status bits */
 #define ORC_S_UTURN_NO_EDGE 1  /* reference raises TypeError at car.py:143 */
@@ -154,6 +155,22 @@ void orc_step_batch_terms(const orc_map*, const orc_car*, const orc_cam*, int N,
                           uint8_t* obs, uint8_t* needs_reset, const int32_t* spawn_queue, int spawn_queue_len,
                           int32_t* spawn_cursor, int n_threads, const orc_term* terms, int n_terms,
                           int32_t* counters);
+/* everything optional a batched step can carry; NULL / zero fields switch the feature off */
+typedef struct {
+  const orc_term* terms;
+  int32_t n_terms;
+  int32_t* counters;          /* [N][ORC_MAX_TERMS] */
+  const int32_t* spawn_table; /* ORC_F_DEVICE_SPAWN: spawnable candidate nodes */
+  int32_t spawn_n;
+  uint64_t spawn_seed;
+} orc_step_ext;
+void orc_step_batch_ext(const orc_map*, const orc_car*, const orc_cam*, int N, orc_state* st, const double* car_control,
+                        const int32_t* maneuver, uint32_t flags, orc_info* info, uint8_t* obs, uint8_t* needs_reset,
+                        const int32_t* spawn_queue, int spawn_queue_len, int32_t* spawn_cursor, int n_threads,
+                        const orc_step_ext* ext);
+/* tinycarlo_amd/csrc/tc_rng.h, exported for the known-answer tests */
+uint64_t orc_splitmix64_at(uint64_t seed, uint64_t n);
+uint32_t orc_spawn_index(uint64_t seed, uint32_t env, uint32_t cursor, uint32_t count);
 int64_t orc_obs_bytes(const orc_map*, const orc_cam*);
 
 #ifdef __cplusplus

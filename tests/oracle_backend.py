@@ -83,7 +83,10 @@ class OracleVecEnv(TinyCarloVecEnv):
     def _oflags(self):
         f = self._flags()
         return (orc.F_NO_OBSERVATION if f & nat.F_NO_OBSERVATION else 0) | (orc.F_WRAPPED if f & nat.F_WRAPPED else 0) | \
-               (orc.F_AUTORESET if f & nat.F_AUTORESET else 0)
+               (orc.F_AUTORESET if f & nat.F_AUTORESET else 0) | (orc.F_DEVICE_SPAWN if f & nat.F_DEVICE_SPAWN else 0)
+
+    def _push_spawn_table(self, tab, seed):
+        self._o.spawn_table, self._o.spawn_seed = np.array(tab, dtype=np.int32), seed
 
     def reset_to(self, spawn_nodes, mask=None):
         self._push()

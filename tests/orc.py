@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(ROOT, "oracle", "libtc_oracle.so")
 MAXC = 16
 MATH_LIBM, MATH_PORTABLE = 0, 1
 FMT_RGB, FMT_CLASSES = 0, 1
-F_NO_OBSERVATION, F_WRAPPED, F_AUTORESET = 1, 2, 4
+F_NO_OBSERVATION, F_WRAPPED, F_AUTORESET, F_DEVICE_SPAWN = 1, 2, 4, 8
 
 
 class Car(C.Structure):
@@ -92,6 +92,12 @@ def lib():
         L.orc_step_batch_terms.argtypes = [C.c_void_p, C.POINTER(Car), C.POINTER(Cam), C.c_int, C.c_void_p, dp, ip,
                                            C.c_uint32, C.c_void_p, bp, bp, ip, C.c_int, ip, C.c_int,
                                            C.c_void_p, C.c_int, ip]
+        L.orc_step_batch_ext.argtypes = [C.c_void_p, C.POINTER(Car), C.POINTER(Cam), C.c_int, C.c_void_p, dp, ip,
+                                         C.c_uint32, C.c_void_p, bp, bp, ip, C.c_int, ip, C.c_int, C.POINTER(StepExt)]
+        L.orc_splitmix64_at.restype = C.c_uint64
+        L.orc_splitmix64_at.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_spawn_index.restype = C.c_uint32
+        L.orc_spawn_index.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_apply_terms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, ip]
         L.orc_linear_reward.restype = C.c_double
         L.orc_linear_reward.argtypes = [C.c_double] * 4
@@ -167,6 +173,11 @@ class Term(C.Structure):  # orc_term (same layout as tc_term)
                 ("p", C.c_double * 4), ("per_layer", C.c_double * 16)]
 
 
+class StepExt(C.Structure):  # orc_step_ext
+    _fields_ = [("terms", C.c_void_p), ("n_terms", C.c_int32), ("counters", C.c_void_p), ("spawn_table", C.c_void_p),
+                ("spawn_n", C.c_int32), ("spawn_seed", C.c_uint64)]
+
+
 def make_terms(terms):
     """ctypes orc_term array from tinycarlo_amd.terms.Term objects"""
     arr = (Term * max(len(terms), 1))()
@@ -195,6 +206,8 @@ class Oracle:
         self.spawn_queue = np.zeros((n, 1), dtype=np.int32)
         self.terms = []                                            # tinycarlo_amd.terms.Term, innermost first
         self.term_counters = np.zeros((n, MAX_TERMS), dtype=np.int32)
+        self.spawn_table = None                                    # F_DEVICE_SPAWN: int32 candidates + seed
+        self.spawn_seed = 0
 
     def set_camera(self, camera):
         fmt = self.cam.format
@@ -217,10 +230,16 @@ class Oracle:
         mn = np.ascontiguousarray(maneuver, dtype=np.int32).reshape(self.n)
         sq = np.ascontiguousarray(self.spawn_queue, dtype=np.int32)
         tarr = make_terms(self.terms)
-        lib().orc_step_batch_terms(self.map.h, C.byref(self.car), C.byref(self.cam), self.n, self.state.ctypes.data,
-                                   _dp(cc), _ip(mn), flags, self.info.ctypes.data, _bp(self.obs) if with_obs else None,
-                                   _bp(self.needs_reset), _ip(sq), sq.shape[1], _ip(self.spawn_cursor), self.threads,
-                                   C.cast(tarr, C.c_void_p), len(self.terms), _ip(self.term_counters))
+        ext = StepExt()
+        ext.terms, ext.n_terms = C.cast(tarr, C.c_void_p), len(self.terms)
+        ext.counters = self.term_counters.ctypes.data
+        if self.spawn_table is not None:
+            tab = np.ascontiguousarray(self.spawn_table, dtype=np.int32)
+            ext.spawn_table, ext.spawn_n, ext.spawn_seed = tab.ctypes.data, int(tab.size), int(self.spawn_seed)
+        lib().orc_step_batch_ext(self.map.h, C.byref(self.car), C.byref(self.cam), self.n, self.state.ctypes.data,
+                                 _dp(cc), _ip(mn), flags, self.info.ctypes.data, _bp(self.obs) if with_obs else None,
+                                 _bp(self.needs_reset), _ip(sq), sq.shape[1], _ip(self.spawn_cursor), self.threads,
+                                 C.byref(ext))
 
     def segments(self, i: int = 0, cap: int = 4096):
         if getattr(self, "_segbuf", None) is None or len(self._segbuf[0]) < cap:

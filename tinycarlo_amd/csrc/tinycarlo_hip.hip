@@ -21,6 +21,7 @@
 
 #include "../../include/tinycarlo_hip.h"
 #include "tc_device.h"
+#include "tc_rng.h"
 
 #define TC_PROF_RING 64
 #define TC_MAX_SPLIT 8
@@ -69,6 +70,9 @@ struct KArgs {
   const tc_term* terms;  // device table [TC_MAX_TERMS] (library owned); reward / termination wrappers
   int n_terms;
   int* term_counters;    // [N][TC_MAX_TERMS] (caller owned)
+  const int* spawn_tab;  // TC_F_DEVICE_SPAWN: spawnable candidate nodes (library owned), spawn_n > 0 entries
+  int spawn_n;
+  unsigned long long spawn_seed;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -322,7 +326,11 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
   } else if (mode == MODE_STEP) {
     if ((flags & TC_F_AUTORESET) && b.needs_reset[env]) {
       int cur = b.spawn_cursor[env];
-      int node = b.spawn_queue[(size_t)env * b.spawn_queue_len + ((unsigned)cur % (unsigned)b.spawn_queue_len)];
+      int node;
+      if ((flags & TC_F_DEVICE_SPAWN) && a.spawn_n > 0)
+        node = a.spawn_tab[tc_spawn_index(a.spawn_seed, (uint32_t)env, (uint32_t)cur, (uint32_t)a.spawn_n)];
+      else
+        node = b.spawn_queue[(size_t)env * b.spawn_queue_len + ((unsigned)cur % (unsigned)b.spawn_queue_len)];
       d_reset(m, a.car, s, checked_spawn(m, node, status));
       fresh = true;
       have_trig = true;
@@ -1322,6 +1330,7 @@ extern "C" int tc_env_destroy(tc_env* e) {
   if (e && e->k.seg_g) (void)hipFree(e->k.seg_g);
   if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
   if (e && e->k.terms) (void)hipFree((void*)e->k.terms);
+  if (e && e->k.spawn_tab) (void)hipFree((void*)e->k.spawn_tab);
   delete e;
   return TC_OK;
 }
@@ -1350,6 +1359,33 @@ extern "C" int tc_env_set_camera_per_env(tc_env* e, const double* E, const doubl
   if (!e || ((E == nullptr) != (K == nullptr))) return TC_E_INVALID;
   e->k.cam_E = E;
   e->k.cam_K = K;
+  return TC_OK;
+}
+
+extern "C" int tc_env_set_spawn_table(tc_env* e, const int32_t* nodes, int32_t n, uint64_t seed) {
+  if (!e || n < 0 || (n > 0 && !nodes)) {
+    set_err("tc_env_set_spawn_table: need n >= 0 and a node array");
+    return TC_E_INVALID;
+  }
+  for (int i = 0; i < n; i++)
+    if (nodes[i] < 0 || nodes[i] >= e->k.m.lpN) {
+      set_err("tc_env_set_spawn_table: node id out of range");
+      return TC_E_INVALID;
+    }
+  HIP_TRY(hipDeviceSynchronize());  // launches in flight still read the old table
+  if (e->k.spawn_tab) {
+    HIP_TRY(hipFree((void*)e->k.spawn_tab));
+    e->k.spawn_tab = nullptr;
+  }
+  e->k.spawn_n = 0;
+  if (n > 0) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, sizeof(int32_t) * (size_t)n));
+    HIP_TRY(hipMemcpy(p, nodes, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    e->k.spawn_tab = (const int*)p;
+    e->k.spawn_n = n;
+  }
+  e->k.spawn_seed = seed;
   return TC_OK;
 }
 
@@ -1461,6 +1497,10 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   }
   if ((flags & TC_F_AUTORESET) && !e->k.b.needs_reset) {
     set_err("TC_F_AUTORESET needs needs_reset/spawn_queue/spawn_cursor buffers");
+    return TC_E_INVALID;
+  }
+  if ((flags & TC_F_DEVICE_SPAWN) && e->k.spawn_n < 1) {
+    set_err("TC_F_DEVICE_SPAWN needs a table (tc_env_set_spawn_table)");
     return TC_E_INVALID;
   }
   const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;

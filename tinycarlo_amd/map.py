@@ -103,6 +103,17 @@ class Map:
                 return idx
         raise RuntimeError("no spawnable lanepath node found")
 
+    def spawn_table(self) -> np.ndarray:
+        """The candidates of ``Map.sample_spawn`` (map.py:61: ``spawn_points``, or node ids ``0..len-2``) that have an
+        out-edge, duplicates kept: a uniform draw from it is distributed like the draw-again-on-sinks loop of
+        map.py:62-64.  Used by the device-side spawn sampling (``tc_env_set_spawn_table``)."""
+        has_next = self._has_next()
+        cand = range(len(self.lanepath.nodes) - 1) if self.spawn_points is None else [int(p) for p in self.spawn_points]
+        tab = np.array([c for c in cand if has_next[c]], dtype=np.int32)
+        if tab.size == 0:
+            raise RuntimeError("no spawnable lanepath node found")
+        return tab
+
     def _has_next(self) -> np.ndarray:
         hn = getattr(self, "_hn", None)
         if hn is None:

@@ -54,7 +54,8 @@ class TinyCarloVecEnv(gym.Env):
 
     def __init__(self, config: Union[str, Dict[str, Any]], num_envs: Optional[int] = None,
                  device: Union[None, str, torch.device] = None, render_mode: Optional[str] = None,
-                 return_numpy: bool = False, autoreset: bool = False, spawn_queue_len: int = 64):
+                 return_numpy: bool = False, autoreset: bool = False, spawn_queue_len: int = 64,
+                 spawn: str = "host"):
         self.config, self.config_path = load_config(config)
         sim = self.config["sim"]
         self.fps: int = sim.get("fps", 30)
@@ -71,6 +72,13 @@ class TinyCarloVecEnv(gym.Env):
         self.render_mode = render_mode
         self.return_numpy = return_numpy
         self.autoreset = autoreset
+        # where autoreset takes its spawn nodes from: "host" = drawn by the per-env numpy generators into a queue
+        # the kernel consumes cyclically (reproduces the reference env reset with seed + i for the first
+        # spawn_queue_len re-spawns); "device" = counter-based draw in the kernel (csrc/tc_rng.h), never repeats,
+        # no host work, not seed-compatible with the reference's numpy generator
+        if spawn not in ("host", "device"):
+            raise ValueError("spawn must be 'host' or 'device'")
+        self.spawn = spawn
         self._debug_flags = int(os.environ.get("TC_DEBUG_FLAGS", "0"), 0)  # profiling ablations only
         self.wrapped = False          # env.py:56
         self.no_observation = False   # env.py:60
@@ -161,6 +169,8 @@ class TinyCarloVecEnv(gym.Env):
             f |= nat.F_WRAPPED
         if self.autoreset:
             f |= nat.F_AUTORESET
+            if self.spawn == "device":
+                f |= nat.F_DEVICE_SPAWN
         return f | self._debug_flags
 
     def _stream(self) -> int:
@@ -251,6 +261,18 @@ class TinyCarloVecEnv(gym.Env):
                 nodes[i] = self.map.sample_spawn_node(self._rngs[i])
         return nodes
 
+    def set_spawn_seed(self, seed: int) -> None:
+        """(re)starts the device-side spawn stream: uploads the spawn table with `seed`, clears the re-spawn counters"""
+        tab = np.ascontiguousarray(self.map.spawn_table(), dtype=np.int32)
+        self._push_spawn_table(tab, int(seed) & 0xFFFFFFFFFFFFFFFF)
+        self._aux["spawn_cursor"].zero_()
+        self.spawn_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    def _push_spawn_table(self, tab: np.ndarray, seed: int) -> None:
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_env_set_spawn_table(self._h, tab.ctypes.data, int(tab.size), seed),
+                      "tc_env_set_spawn_table")
+
     def refill_spawn_queue(self) -> None:
         """Pre-draws `spawn_queue_len` spawn nodes per env for device-side auto-reset (consumed cyclically)."""
         q = np.zeros((self.num_envs, self.spawn_queue_len), dtype=np.int32)
@@ -267,7 +289,10 @@ class TinyCarloVecEnv(gym.Env):
         mk_np = None if mask is None else np.asarray(mask.cpu() if isinstance(mask, torch.Tensor) else mask).astype(bool)
         nodes = self.draw_spawn_nodes(mk_np)
         if self.autoreset and (seed is not None or not self._was_reset):
-            self.refill_spawn_queue()
+            if self.spawn == "device":
+                self.set_spawn_seed(seed if seed is not None else 0)
+            else:
+                self.refill_spawn_queue()
         self.reset_to(nodes, mk_np)
         return self._obs(), self._info()
 
