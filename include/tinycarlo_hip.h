@@ -198,7 +198,7 @@ int64_t tc_env_lds_bytes(const tc_env* env);
  * stream around its two kernels ("simulate": kinematics + tracking + distances + camera geometry; "raster":
  * cv2.polylines + observation store) into a ring of the last 64 launches.  tc_env_profile_read waits for
  * those launches and returns their mean durations in microseconds.  When a step is issued as ONE fused kernel
- * (the default for maps up to 512 lane-line nodes / edges; env var TC_FUSE=0 forces two launches), simulate_us is
+ * (the default unless a lane-line layer has more than 576 nodes / edges; env var TC_FUSE=0 forces two launches), simulate_us is
  * the duration of that kernel and raster_us is ~0. */
 int tc_env_profile(tc_env* env, int32_t enable);
 int tc_env_profile_read(tc_env* env, double* simulate_us, double* raster_us, int32_t* launches);

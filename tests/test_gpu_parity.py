@@ -331,14 +331,17 @@ def test_step_captures_into_a_hip_graph():
     env_e.close()
 
 
-def test_large_synthetic_map_multi_window(tmp_path):
-    """A map beyond the single-window register cache (13*64 nodes / edges) and beyond 48 KB of LDS: knuffingen's
-    lane-line layers three times over (15 layers, 2481 nodes, 2217 edges).  Exercises the window loop of
-    tc_env_kernel<13>, C = 15 class planes and the dynamic-LDS attribute path."""
+@pytest.mark.parametrize("groups", ["0", "1"])
+def test_large_synthetic_map_multi_window(tmp_path, groups, monkeypatch):
+    """A map beyond the single-window register cache (13*64 nodes / edges): knuffingen's lane-line layers three times
+    over (15 layers, 2481 nodes, 2217 edges).  TC_GROUPS=0: one camera group, the window loop of tc_env_kernel<13>
+    and more than 48 KB of LDS (dynamic-LDS attribute path).  TC_GROUPS=1 (default): six camera layer groups on the
+    K = 9 kernel, phase B over five node windows.  C = 15 class planes either way."""
     import json
     import os
     from tinycarlo_amd.config import bundled_config
     from tinycarlo_amd.vec_env import TinyCarloVecEnv
+    monkeypatch.setenv("TC_GROUPS", groups)
     cfg, path = load_cfg("knuffingen")
     cfg = copy.deepcopy(cfg)
     src = os.path.join(os.path.dirname(path), cfg["map"]["json_path"])
@@ -360,7 +363,7 @@ def test_large_synthetic_map_multi_window(tmp_path):
         cfg["sim"]["observation_space_format"] = fmt
         N = 48
         env = TinyCarloVecEnv(cfg, num_envs=N, device="cuda:0", autoreset=True, spawn_queue_len=4)
-        assert env.n_classes == 15 and env.lds_bytes > 48 * 1024
+        assert env.n_classes == 15 and (env.lds_bytes > 48 * 1024) == (groups == "0")
         o = make_oracle(env)
         env.reset(seed=77)
         o.spawn_queue = env._aux["spawn_queue"].cpu().numpy()
@@ -576,5 +579,35 @@ def test_mid_sized_map_k8_variant(tmp_path, fuse_env, monkeypatch):
             o.step(cc, man, flags=orc.F_AUTORESET)
             env.step({"car_control": cc, "maneuver": man})
             assert_same(env, o, env.n_classes, check_obs=(t % 4 == 3), label=f"mid map {fmt} fuse={fuse_env} step {t}")
+        assert int(env.out["obs"].max()) > 0
+        env.close()
+
+
+@pytest.mark.parametrize("groups,fuse", [("1", "1"), ("1", "0"), ("0", "1")])
+def test_knuffingen_kernel_variants_agree_with_oracle(groups, fuse, monkeypatch):
+    """knuffingen (827 nodes) three ways: camera layer groups on the K = 9 kernel, fused and as two launches, and
+    the single-group K = 13 two-launch path (TC_GROUPS=0) -- same bits as the oracle in each."""
+    monkeypatch.setenv("TC_GROUPS", groups)
+    monkeypatch.setenv("TC_FUSE", fuse)
+    N = 160
+    for fmt, rk, th in (("classes", "r128", 2), ("rgb", "r64", 3)):
+        env = make_env("knuffingen", rk, fmt, N, autoreset=True, spawn_queue_len=4, camera={"line_thickness": th})
+        assert (env.lds_bytes < 24 * 1024) == (groups == "1")
+        o = make_oracle(env)
+        env.reset(seed=8)
+        o.spawn_queue = env._aux["spawn_queue"].cpu().numpy()
+        o.reset(env._keep[0].cpu().numpy())
+        assert_same(env, o, env.n_classes, label="reset")
+        rng = np.random.default_rng(6)
+        env.profile(1)
+        for t in range(20):
+            cc = np.stack([rng.uniform(-0.2, 1.1, N), rng.uniform(-1.1, 1.1, N)], axis=1)
+            man = rng.integers(0, 4, N).astype(np.int32)
+            o.step(cc, man, flags=orc.F_AUTORESET)
+            env.step({"car_control": cc, "maneuver": man})
+            assert_same(env, o, env.n_classes, check_obs=(t % 4 == 3), label=f"knuffingen groups={groups} fuse={fuse} {fmt} step {t}")
+        p = env.profile_read()
+        one_launch = groups == "1" and fuse == "1"
+        assert (p["raster_us"] < 0.25 * p["simulate_us"]) == one_launch, p
         assert int(env.out["obs"].max()) > 0
         env.close()

@@ -49,6 +49,7 @@
 #define R_OFF_BITS ((R_TAB_BYTES + 15) / 16 * 16)
 #define LCH 8        // outline steps per chunk
 
+#define TC_MAX_GROUPS 8
 struct LdsLayout {
   int off_p, off_flg, off_list, off_cnt;
   int total;
@@ -70,6 +71,11 @@ struct KArgs {
   const tc_term* terms;  // device table [TC_MAX_TERMS] (library owned); reward / termination wrappers
   int n_terms;
   int* term_counters;    // [N][TC_MAX_TERMS] (caller owned)
+  // camera layer groups: phase C handles lane-line layers grp_layer[g] .. grp_layer[g+1]-1 together (camera.py's
+  // per-layer loop makes the layers independent); the LDS node buffer holds cap_nodes nodes, the largest group
+  int n_grp;
+  int grp_layer[TC_MAX_GROUPS + 1];
+  int cap_nodes;
   const int* spawn_tab;  // TC_F_DEVICE_SPAWN: spawnable candidate nodes (library owned), spawn_n > 0 entries
   int spawn_n;
   unsigned long long spawn_seed;
@@ -146,20 +152,23 @@ struct MapCache {
   int2 ed[K];
 };
 
+// slot k of lane tid <-> node (edge) base + k*64 + tid, valid below `end`
 template <int K>
-__device__ inline void cache_nodes(MapCache<K>& c, const DevMap& m, int w) {
+__device__ inline void cache_nodes(MapCache<K>& c, const DevMap& m, int base, int end) {
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    const int i = (w * K + k) * TC_NT + threadIdx.x;
-    c.nd[k] = i < m.total_nodes ? m.nodes[i] : make_double2(0.0, 0.0);
+    const int i = base + k * TC_NT + threadIdx.x;
+    c.nd[k] = i < end ? m.nodes[i] : make_double2(0.0, 0.0);
   }
 }
+// node ids are stored relative to `nbase` (the first node of the camera group; 0 for whole-map use)
 template <int K>
-__device__ inline void cache_edges(MapCache<K>& c, const DevMap& m, int w) {
+__device__ inline void cache_edges(MapCache<K>& c, const DevMap& m, int base, int end, int nbase) {
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    const int e = (w * K + k) * TC_NT + threadIdx.x;
-    c.ed[k] = e < m.total_edges ? m.edges_g[e] : make_int2(0, 0);
+    const int e = base + k * TC_NT + threadIdx.x;
+    int2 ed = e < end ? m.edges_g[e] : make_int2(nbase, nbase);
+    c.ed[k] = make_int2(ed.x - nbase, ed.y - nbase);
   }
 }
 
@@ -169,14 +178,14 @@ __device__ inline void cache_edges(MapCache<K>& c, const DevMap& m, int w) {
 // the "other" end within one pass), so each target node's chain is replayed in ascending edge
 // index by the lane that owns the chain's first edge.  List entries carry (edge, target | other << 16)
 // so the chain loops touch LDS only.
+// Works on one camera group: edges ge0 .. ge0+ne-1 (ids below are relative to ge0), node ids relative to gn0.
 template <int K>
-__device__ inline void cam_fixup_pass(MapCache<K>& mc, const DevMap& m, bool single, int nwin, double* Px, double* Py,
-                                      double* Pz, unsigned char* flg, int bit, bool target_e0, double tz, int* list,
-                                      int* cnt) {
+__device__ inline void cam_fixup_pass(MapCache<K>& mc, const DevMap& m, bool reload, int ge0, int ne, int gn0, int nwin,
+                                      double* Px, double* Py, double* Pz, unsigned char* flg, int bit, bool target_e0,
+                                      double tz, int* list, int* cnt) {
   const int tid = threadIdx.x;  // *cnt was zeroed (and a barrier passed) before the call
-  const int ne = m.total_edges;
   for (int w = 0; w < nwin; w++) {
-    if (!single) cache_edges(mc, m, w);
+    if (reload) cache_edges(mc, m, ge0 + w * K * TC_NT, ge0 + ne, gn0);
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const int e = (w * K + k) * TC_NT + tid;
@@ -284,15 +293,15 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
   const tc_buffers& b = a.b;
   // map windows of 64*K nodes / edges; one window (the usual case) is fetched now and kept in registers
   const int nwin_n = (m.total_nodes + TC_NT * K - 1) / (TC_NT * K), nwin_e = (m.total_edges + TC_NT * K - 1) / (TC_NT * K);
-  const bool single = nwin_n <= 1 && nwin_e <= 1;
+  const bool single = a.n_grp == 1 && nwin_n <= 1 && nwin_e <= 1;
   MapCache<K> mc;
   if (single) {
-    cache_nodes(mc, m, 0);
-    cache_edges(mc, m, 0);
+    cache_nodes(mc, m, 0, m.total_nodes);
+    cache_edges(mc, m, 0, m.total_edges, 0);
   }
   double* Px = (double*)(smem + a.lds.off_p);
-  double* Py = Px + m.total_nodes;
-  double* Pz = Py + m.total_nodes;
+  double* Py = Px + a.cap_nodes;
+  double* Pz = Py + a.cap_nodes;
   double* dn = Px;  // phase B alias
   unsigned char* flg = smem + a.lds.off_flg;
   int* list = (int*)(smem + a.lds.off_list);
@@ -411,7 +420,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     double dist_l = 0;  // lane l < C: distance to lane-line layer l (0 while the info is empty, car.py:47-51)
     if (have_info && !(flags & DBG_SKIP_DIST)) {
       for (int w = 0; w < nwin_n; w++) {
-        if (!single) cache_nodes(mc, m, w);
+        if (!single) cache_nodes(mc, m, w * K * TC_NT, m.total_nodes);
 #pragma unroll
         for (int k = 0; k < K; k++) {
           const int i = (w * K + k) * TC_NT + tid;
@@ -425,7 +434,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
         int best = -1;
         double bd = 0;
         for (int w = 0; w < nwin_e; w++) {
-          if (!single) cache_edges(mc, m, w);
+          if (!single) cache_edges(mc, m, w * K * TC_NT, m.total_edges, 0);
 #pragma unroll
           for (int k = 0; k < K; k++) {  // layer.py:43 over this lane's edges of layer l (ascending index)
             const int e = (w * K + k) * TC_NT + tid;
@@ -503,85 +512,99 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     d_matmul<4, 4, 4>(R, Tm, car3d);
     d_matmul<3, 4, 4>(Ec, car3d, pose);  // camera.py:62
   }
-  // All lane-line layers are processed together: node ids are made global (edges_g), so each of the
-  // passes below is ONE loop over all nodes / edges instead of one per layer (the layers never share
-  // nodes, so camera.py's per-layer loop and this are the same computation).
+  // The lane-line layers of a camera group are processed together: node ids are made global (edges_g) and then
+  // relative to the group, so each of the passes below is ONE loop over the group's nodes / edges instead of one
+  // per layer (the layers never share nodes, so camera.py's per-layer loop and this are the same computation).
+  // Small maps are a single group; larger ones are split by the host so that the node buffer (and with it the
+  // number of workgroups a CU can hold) is sized by the largest group instead of the whole map.
   // counters: cnt[0..3] fix-up passes, cnt[4] projection candidates, cnt[5] draw list
   int* seg_cnt = cnt + 5;
   int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;  // [seg_cap][5]: layer, x0, y0, x1, y1
-  if (tid < 6) cnt[tid] = 0;
-  const int nn = m.total_nodes, ne = m.total_edges;
-  for (int w = 0; w < nwin_n; w++) {  // camera.py:124-131
-    if (!single) cache_nodes(mc, m, w);
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      const int i = (w * K + k) * TC_NT + tid;
-      if (i < nn) {
-        double h[4] = {mc.nd[k].x, mc.nd[k].y, 0.0, 1.0};
-        double p[3];
-        d_matmul<3, 4, 1>(pose, h, p);
-        Px[i] = p[0];
-        Py[i] = p[1];
-        Pz[i] = p[2];
-        flg[i] = p[2] < 0 ? 1 : 0;  // camera.py:70
-      }
+  if (tid == 5) cnt[5] = 0;
+  for (int g = 0; g < a.n_grp; g++) {
+    const int l0 = a.grp_layer[g], l1 = a.grp_layer[g + 1];
+    const int gn0 = m.node_off[l0], ge0 = m.edge_off[l0];
+    const int nn = m.node_off[l1] - gn0, ne = m.edge_off[l1] - ge0;
+    const int nwn = (nn + TC_NT * K - 1) / (TC_NT * K), nwe = (ne + TC_NT * K - 1) / (TC_NT * K);
+    const bool one = nwn <= 1 && nwe <= 1;  // the group fits the register cache: loaded once, serves every pass
+    const bool reload = !one;
+    if (one && !single) {
+      cache_nodes(mc, m, gn0, gn0 + nn);
+      cache_edges(mc, m, ge0, ge0 + ne, gn0);
     }
-  }
-  __syncthreads();
-  cam_fixup_pass(mc, m, single, nwin_e, Px, Py, Pz, flg, 1, true, -0.0000001, list, cnt + 0);   // camera.py:71-74
-  cam_fixup_pass(mc, m, single, nwin_e, Px, Py, Pz, flg, 1, false, -0.0000001, list, cnt + 1);  // camera.py:75-77
-  for (int i = tid; i < nn; i += TC_NT)
-    if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
-  __syncthreads();
-  cam_fixup_pass(mc, m, single, nwin_e, Px, Py, Pz, flg, 2, true, -cam.max_range, list, cnt + 2);   // camera.py:81-83
-  cam_fixup_pass(mc, m, single, nwin_e, Px, Py, Pz, flg, 2, false, -cam.max_range, list, cnt + 3);  // camera.py:84-86
-  // Only nodes in front AND in range can be "visible" (camera.py:92-93): compact them so the two f64
-  // divisions of the projection are paid for those nodes only.
-  for (int i = tid; i < nn; i += TC_NT)
-    if ((flg[i] & 3) == 3) list[atomicAdd(cnt + 4, 1)] = i;
-  __syncthreads();
-  const int ncand = cnt[4];
-  for (int k = tid; k < ncand; k += TC_NT) {  // camera.py:133-142, 90
-    const int i = list[k];
-    double u, v;
-    int2 q = cam_project(Kc, Px[i], Py[i], Pz[i], u, v);
-    bool vis = (u > 0) && (u < cam.W) && (v > 0) && (v < cam.H);
-    ((int2*)Px)[i] = q;  // renderer.py:43,50 np.int32(...)
-    flg[i] |= vis ? (4 | 8) : 8;  // 8: slot Px[i] now holds the int32 pixel coordinates
-  }
-  __syncthreads();
-  for (int w = 0; w < nwin_e; w++) {  // camera.py:95
-    if (!single) cache_edges(mc, m, w);
+    if (tid < 5) cnt[tid] = 0;
+    for (int w = 0; w < nwn; w++) {  // camera.py:124-131
+      if (reload) cache_nodes(mc, m, gn0 + w * K * TC_NT, gn0 + nn);
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-      const int e = (w * K + k) * TC_NT + tid;
-      if (e < ne) {
-        const int2 ed = mc.ed[k];
-        const int fa = flg[ed.x], fb = flg[ed.y];
-        if ((fa | fb) & 4) {
-          double u, v;
-          int2 pa = (fa & 8) ? ((int2*)Px)[ed.x] : cam_project(Kc, Px[ed.x], Py[ed.x], Pz[ed.x], u, v);
-          int2 pb = (fb & 8) ? ((int2*)Px)[ed.y] : cam_project(Kc, Px[ed.y], Py[ed.y], Pz[ed.y], u, v);
-          int layer = 0;
-          for (int c = 1; c < m.C; c++) layer += e >= m.edge_off[c];
-          int j = atomicAdd(seg_cnt, 1);
-          int* o = segg + 5 * j;  // j < seg_cap == total edge count
-          o[0] = layer;
-          o[1] = pa.x;
-          o[2] = pa.y;
-          o[3] = pb.x;
-          o[4] = pb.y;
+      for (int k = 0; k < K; k++) {
+        const int i = (w * K + k) * TC_NT + tid;
+        if (i < nn) {
+          double h[4] = {mc.nd[k].x, mc.nd[k].y, 0.0, 1.0};
+          double p[3];
+          d_matmul<3, 4, 1>(pose, h, p);
+          Px[i] = p[0];
+          Py[i] = p[1];
+          Pz[i] = p[2];
+          flg[i] = p[2] < 0 ? 1 : 0;  // camera.py:70
         }
       }
     }
+    __syncthreads();
+    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, true, -0.0000001, list, cnt + 0);   // camera.py:71-74
+    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, false, -0.0000001, list, cnt + 1);  // camera.py:75-77
+    for (int i = tid; i < nn; i += TC_NT)
+      if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
+    __syncthreads();
+    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, true, -cam.max_range, list, cnt + 2);   // camera.py:81-83
+    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, false, -cam.max_range, list, cnt + 3);  // camera.py:84-86
+    // Only nodes in front AND in range can be "visible" (camera.py:92-93): compact them so the two f64
+    // divisions of the projection are paid for those nodes only.
+    for (int i = tid; i < nn; i += TC_NT)
+      if ((flg[i] & 3) == 3) list[atomicAdd(cnt + 4, 1)] = i;
+    __syncthreads();
+    const int ncand = cnt[4];
+    for (int k = tid; k < ncand; k += TC_NT) {  // camera.py:133-142, 90
+      const int i = list[k];
+      double u, v;
+      int2 q = cam_project(Kc, Px[i], Py[i], Pz[i], u, v);
+      bool vis = (u > 0) && (u < cam.W) && (v > 0) && (v < cam.H);
+      ((int2*)Px)[i] = q;  // renderer.py:43,50 np.int32(...)
+      flg[i] |= vis ? (4 | 8) : 8;  // 8: slot Px[i] now holds the int32 pixel coordinates
+    }
+    __syncthreads();
+    for (int w = 0; w < nwe; w++) {  // camera.py:95
+      if (reload) cache_edges(mc, m, ge0 + w * K * TC_NT, ge0 + ne, gn0);
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const int e = (w * K + k) * TC_NT + tid;
+        if (e < ne) {
+          const int2 ed = mc.ed[k];
+          const int fa = flg[ed.x], fb = flg[ed.y];
+          if ((fa | fb) & 4) {
+            double u, v;
+            int2 pa = (fa & 8) ? ((int2*)Px)[ed.x] : cam_project(Kc, Px[ed.x], Py[ed.x], Pz[ed.x], u, v);
+            int2 pb = (fb & 8) ? ((int2*)Px)[ed.y] : cam_project(Kc, Px[ed.y], Py[ed.y], Pz[ed.y], u, v);
+            int layer = l0;
+            for (int c = l0 + 1; c < l1; c++) layer += (ge0 + e) >= m.edge_off[c];
+            int j = atomicAdd(seg_cnt, 1);
+            int* o = segg + 5 * j;  // j < seg_cap == total edge count
+            o[0] = layer;
+            o[1] = pa.x;
+            o[2] = pa.y;
+            o[3] = pb.x;
+            o[4] = pb.y;
+          }
+        }
+      }
+    }
+    __syncthreads();  // the next group reuses the node buffer and the counters
   }
-  __syncthreads();
   if (tid == 0) a.seg_n[env] = *seg_cnt;  // handed to the raster stage through global memory
   return true;
 }
 
 template <int K>
-__global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 8 ? 3 : 2)) void tc_env_kernel(KArgs a, int mode, const void* car_control, int cdtype,
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) void tc_env_kernel(KArgs a, int mode, const void* car_control, int cdtype,
                                                        const int* maneuver, const int* spawn_nodes,
                                                        const unsigned char* mask, unsigned int flags) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -914,7 +937,7 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
 // Both stages in one launch: the same wavefront simulates its env and then rasterises it.  Saves one kernel
 // boundary (launch gap + one ramp-up / drain of the whole grid) per step.
 template <int K, bool THICK, int FMT>
-__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 8 ? 3 : 2)) void tc_step_kernel(KArgs a, RArgs r, int mode, const void* car_control,
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_kernel(KArgs a, RArgs r, int mode, const void* car_control,
                                                                      int cdtype, const int* maneuver, const int* spawn_nodes,
                                                                      const unsigned char* mask, unsigned int flags) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -968,6 +991,7 @@ struct tc_env {
   // the overlap gains, so it stays off.
   int split;
   int fuse;  // 1: simulate + raster in one launch (tc_step_kernel); 0: two launches
+  int kvar;  // register-cache slots of the simulate stage: 5, 8 (whole map in one window), 9 (camera layer groups), 13
   hipStream_t side[TC_MAX_SPLIT];
   hipEvent_t fork_ev, join_ev[TC_MAX_SPLIT];
   // optional per-kernel timing: a ring of (start, mid, end) HIP events recorded on the caller's stream
@@ -1219,15 +1243,65 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   if (band_rows > dc.H) band_rows = dc.H;
   dc.band_rows = band_rows;
   dc.n_bands = (dc.H + band_rows - 1) / band_rows;
+  // Camera layer groups.  Up to 512 nodes / edges the whole map is one group held in the K = 5 / 8 register cache.
+  // Beyond that the layers are packed greedily, in order, into groups no larger than the largest single layer:
+  // the LDS node buffer shrinks from the whole map to that layer (knuffingen: 827 -> 517 nodes, 26.6 -> 17.4 KB per
+  // env, 6 -> 8 workgroups per CU) and a K = 9 cache (576 slots) covers a group.  Maps whose largest layer exceeds
+  // 576 nodes or edges, or that would need more than TC_MAX_GROUPS groups, stay one group on the K = 13 windowed path
+  // (env var TC_GROUPS=0 forces that).
+  const int big = m.total_nodes > m.total_edges ? m.total_nodes : m.total_edges;
+  int cap_n = m.total_nodes, cap_e = m.total_edges;
+  e->k.n_grp = 1;
+  e->k.grp_layer[0] = 0;
+  e->k.grp_layer[1] = m.C;
+  e->kvar = big <= 5 * TC_NT ? 5 : big <= 8 * TC_NT ? 8 : 13;
+  bool want_groups = big > 8 * TC_NT;
+  if (const char* sg = getenv("TC_GROUPS")) want_groups = want_groups && atoi(sg) != 0;
+  if (want_groups) {
+    int cap = 0;
+    for (int l = 0; l < m.C; l++) {
+      int nl = m.node_off[l + 1] - m.node_off[l], el = m.edge_off[l + 1] - m.edge_off[l];
+      cap = nl > cap ? nl : cap;
+      cap = el > cap ? el : cap;
+    }
+    if (cap <= 9 * TC_NT) {
+      int lay[TC_MAX_GROUPS + 1], ng = 0, l = 0;
+      bool ok = true;
+      lay[0] = 0;
+      while (l < m.C) {
+        if (ng == TC_MAX_GROUPS) {
+          ok = false;
+          break;
+        }
+        int first = l;
+        while (l < m.C && m.node_off[l + 1] - m.node_off[first] <= cap && m.edge_off[l + 1] - m.edge_off[first] <= cap) l++;
+        lay[++ng] = l;  // l > first: a single layer always fits `cap`
+      }
+      if (ok && ng >= 2) {
+        e->k.n_grp = ng;
+        cap_n = cap_e = 0;
+        for (int g = 0; g <= ng; g++) e->k.grp_layer[g] = lay[g];
+        for (int g = 0; g < ng; g++) {
+          int nl = m.node_off[lay[g + 1]] - m.node_off[lay[g]], el = m.edge_off[lay[g + 1]] - m.edge_off[lay[g]];
+          cap_n = nl > cap_n ? nl : cap_n;
+          cap_e = el > cap_e ? el : cap_e;
+        }
+        e->kvar = 9;
+      }
+    }
+  }
+  e->k.cap_nodes = cap_n > 0 ? cap_n : 1;
   LdsLayout& L = e->k.lds;
   int off = 0;
-  L.off_p = off;  // node buffer: 3 doubles per lane-line node (all layers)
-  int pbytes = 3 * m.total_nodes * 8;
+  L.off_p = off;  // node buffer: 3 doubles per node of the largest camera group; phase B aliases it with one
+                  // double per lane-line node of the whole map
+  int pbytes = 3 * e->k.cap_nodes * 8;
+  if (m.total_nodes * 8 > pbytes) pbytes = m.total_nodes * 8;
   off += align_up(pbytes, 16);
   L.off_flg = off;
-  off += align_up(m.total_nodes, 16);
+  off += align_up(e->k.cap_nodes, 16);
   L.off_list = off;  // fix-up edge list / projection candidate list
-  off += align_up((2 * m.total_edges > m.total_nodes ? 2 * m.total_edges : m.total_nodes) * 4, 16);
+  off += align_up((2 * cap_e > cap_n ? 2 * cap_e : cap_n) * 4 + 16, 16);
   L.off_cnt = off;
   off += 64;
   L.total = off;
@@ -1247,6 +1321,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
         for (int c = 0; c < 2; c++) {
           (void)hipFuncSetAttribute((const void*)pick_fused<5>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_fused<8>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          (void)hipFuncSetAttribute((const void*)pick_fused<9>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
     }
   }
@@ -1259,6 +1334,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   if (L.total > 48 * 1024) {
     hipError_t he = hipFuncSetAttribute((const void*)tc_env_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void*)tc_env_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void*)tc_env_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void*)tc_env_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (he != hipSuccess) {
       set_err(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he));
@@ -1505,8 +1581,8 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   }
   const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;
   const int slot = e->prof_n % TC_PROF_RING;
-  const int big = e->k.m.total_nodes > e->k.m.total_edges ? e->k.m.total_nodes : e->k.m.total_edges;
-  auto kern = big <= 5 * TC_NT ? tc_env_kernel<5> : big <= 8 * TC_NT ? tc_env_kernel<8> : tc_env_kernel<13>;
+  const int kv = e->kvar;
+  auto kern = kv == 5 ? tc_env_kernel<5> : kv == 8 ? tc_env_kernel<8> : kv == 9 ? tc_env_kernel<9> : tc_env_kernel<13>;
   const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
   const int N = e->k.N;
   // sub-batches only pay off with an observation to rasterise and enough envs per part; profiled steps stay whole
@@ -1514,10 +1590,10 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   hipStream_t main = (hipStream_t)stream;
   if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], main));
   if (parts > 1) HIP_TRY(hipEventRecord(e->fork_ev, main));
-  if (do_raster && e->fuse && parts == 1 && big <= 8 * TC_NT) {  // one launch: simulate + raster by the same wavefront
-    // (maps beyond 512 nodes/edges use the register-hungry K = 13 simulate stage: fused it spills, so two launches)
+  if (do_raster && e->fuse && parts == 1 && kv != 13) {  // one launch: simulate + raster by the same wavefront
+    // (the register-hungry K = 13 simulate stage spills when fused, so it stays two launches)
     const bool thick = e->k.cam.thickness > 1, cls = e->k.cam.format == TC_FMT_CLASSES;
-    fused_kern_t fk = big <= 5 * TC_NT ? pick_fused<5>(thick, cls) : pick_fused<8>(thick, cls);
+    fused_kern_t fk = kv == 5 ? pick_fused<5>(thick, cls) : kv == 8 ? pick_fused<8>(thick, cls) : pick_fused<9>(thick, cls);
     KArgs k = e->k;
     k.env0 = 0;
     RArgs r = make_rargs(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, nullptr, flags, 0);
