@@ -17,8 +17,12 @@ CFG = {"simple_layout": "config_simple_layout.yaml", "knuffingen": "config_knuff
 _cache = {}
 
 
+# configs that are test inputs only (tests/golden/): the synthetic stress map of make_stress_map.py
+TEST_CFG = {"stress_graph": "config_stress_graph.yaml"}
+
+
 def load_cfg(map_name):
-    path = bundled_config(CFG[map_name])
+    path = os.path.join(GOLDEN, TEST_CFG[map_name]) if map_name in TEST_CFG else bundled_config(CFG[map_name])
     with open(path) as f:
         return yaml.safe_load(f), path
 
@@ -46,7 +50,7 @@ def rollout_files():
 
 
 def map_of(fname):
-    for name in CFG:
+    for name in list(CFG) + list(TEST_CFG):
         if name in fname:
             return name
     raise KeyError(fname)

@@ -83,6 +83,8 @@ MAPS = {
 EXTRA_MAPS = {
     "formula_student_track": os.path.join(os.path.dirname(os.path.dirname(OUT)), "tinycarlo_amd", "data",
                                           "config_formula_student_track.yaml"),
+    # a synthetic map of this repo (make_stress_map.py): json_path is relative to the config itself
+    "stress_graph": os.path.join(OUT, "config_stress_graph.yaml"),
 }
 RESOLUTIONS = {"r64": [64, 64], "r128": [128, 128], "r480": [480, 640]}
 
@@ -91,7 +93,10 @@ def load(map_name):
     if map_name in EXTRA_MAPS:
         with open(EXTRA_MAPS[map_name]) as f:
             cfg = yaml.safe_load(f)
-        path = os.path.join(REF, "examples", "x.yaml")  # json_path is relative to the reference's examples/
+        if map_name == "stress_graph":
+            path = EXTRA_MAPS[map_name]
+        else:
+            path = os.path.join(REF, "examples", "x.yaml")  # json_path is relative to the reference's examples/
         m = Map(cfg["map"], base_path=path)
     else:
         path = os.path.join(REF, "examples", MAPS[map_name])
@@ -445,6 +450,22 @@ def camera_mats():
     return out
 
 
+def main_stress():
+    """rollouts on the synthetic stress map: hub with 5 successors / predecessors, dead end, self-loops, duplicate and
+    zero-length edges"""
+    for mn, seed, steps, pol, cks, mp in [("stress_graph", 0, 400, "random", ["r64"], 12),
+                                          ("stress_graph", 1, 400, "stanley", ["r128"], 20),
+                                          ("stress_graph", 2, 400, "wild", ["r64"], 6),
+                                          ("stress_graph", 3, 400, "stanley", ["r64"], 9)]:
+        out = rollout(mn, seed, steps, pol, cks, mp)
+        name = f"rollout_{mn}_{pol}_{seed}.npz"
+        np.savez_compressed(os.path.join(OUT, name), **out)
+        print(name, "resets", len(out["reset_step"]), "trunc", int(out["truncated"].sum()), "term", int(out["terminated"].sum()))
+    out = single_steps("stress_graph", 3000, 13)   # every lanepath edge incl. the self-loop, the dead end, the hub spokes
+    np.savez_compressed(os.path.join(OUT, "single_stress_graph.npz"), **out)
+    print("single_stress_graph.npz", len(out["v"]), "trunc", int(out["truncated"].sum()), "exceptions", len(out.get("exc_v", [])))
+
+
 def main_extra():
     """formula_student_track rollouts (added later; the other fixtures are left untouched)"""
     for mn, seed, steps, pol, cks, mp in [("formula_student_track", 0, 300, "stanley", ["r64"], 16),
@@ -590,6 +611,8 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         main_extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == "stress":
+        main_stress()
     elif len(sys.argv) > 1 and sys.argv[1] == "wrappers":
         main_wrappers()
     else:

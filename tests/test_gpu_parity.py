@@ -24,17 +24,15 @@ STATE_F = ("x", "y", "theta", "velocity", "steering", "radius", "front_x", "fron
 
 def make_env(map_name, res_key, fmt, n, **kw):
     from tinycarlo_amd.vec_env import TinyCarloVecEnv
-    cfg, _ = load_cfg(map_name)
+    cfg, cfg_path = load_cfg(map_name)
     cfg = copy.deepcopy(cfg)
     from common import RES
     cfg["camera"]["resolution"] = list(RES[res_key])
     cam_over = kw.pop("camera", {})
     cfg["camera"].update(cam_over)
     cfg["sim"]["observation_space_format"] = fmt
-    from tinycarlo_amd.config import bundled_config
     import os
-    cfg["map"]["json_path"] = os.path.join(os.path.dirname(bundled_config("config_simple_layout.yaml")),
-                                           cfg["map"]["json_path"])
+    cfg["map"]["json_path"] = os.path.join(os.path.dirname(cfg_path), cfg["map"]["json_path"])
     return TinyCarloVecEnv(cfg, num_envs=n, device="cuda:0", **kw)
 
 
@@ -134,7 +132,7 @@ def test_golden_teacher_forced(fname):
     env.close()
 
 
-@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen"])
+@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen", "stress_graph"])
 def test_golden_single_steps(mp):
     d = golden(f"single_{mp}.npz")
     T = len(d["v"])
@@ -164,6 +162,7 @@ CASES = [
     ("simple_layout", "r128", "rgb", 64, 32, 6),         # stanley_control.py thickness
     ("knuffingen", "r480", "rgb", 16, 12, 2),            # BASELINE config 5 shape (banded raster)
     ("simple_layout", "r480", "classes", 8, 8, 3),
+    ("stress_graph", "r64", "classes", 256, 64, 3),      # hub with 5 successors / predecessors, dead end, self-loops
 ]
 
 

@@ -157,7 +157,7 @@ def test_rollout_free_running(fname):
 
 
 @pytest.mark.parametrize("mode,tol", [(orc.MATH_LIBM, FTOL), (orc.MATH_PORTABLE, 1e-9)])
-@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen"])
+@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen", "stress_graph"])
 def test_single_steps(mp, mode, tol):
     """4000 independent (state, action) pairs per map: U-turns, reverse, all maneuvers, truncations."""
     d = golden(f"single_{mp}.npz")
