@@ -91,10 +91,17 @@ __device__ inline double d_linear_reward(double x, double max_x, double max_rewa
   return (min_reward < y) ? min_reward : y;                      // python min(y, min_reward)
 }
 
+// value of lane `l` (wave-uniform index): v_readlane instead of a shuffle through the LDS crossbar
+__device__ __forceinline__ double d_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 // (scalars by value: a reference to the kernel-argument struct would force a copy of it into scratch)
-__device__ __forceinline__ void d_apply_terms(const tc_term* terms, int n_terms, int* counters, double tw, int env,
-                                              int tid, int C, double cte, double vel, double dist_l, double& reward,
-                                              int& terminated) {
+// my_cnt: lane t < TC_MAX_TERMS holds steps_true of term slot t (loaded at kernel start, stored by the caller)
+__device__ __forceinline__ void d_apply_terms(const tc_term* terms, int n_terms, int& my_cnt, double tw, int tid, int C,
+                                              double cte, double vel, double dist_l, double& reward, int& terminated) {
   const double half = tw / 2;
   for (int t = 0; t < n_terms; t++) {
     const tc_term* T = terms + t;
@@ -103,13 +110,13 @@ __device__ __forceinline__ void d_apply_terms(const tc_term* terms, int n_terms,
     if (kind == TC_T_LANELINE_SPARSE_REWARD) {  // reward.py:20-21, utils.py:15-19
       double local = 0.0;
       for (int l = 0; l < C; l++) {
-        const double d = __shfl(dist_l, l);
+        const double d = d_readlane(dist_l, l);
         if (((mask >> l) & 1u) && d < half) local += T->per_layer[l];
       }
       reward = reward + local;
     } else if (kind == TC_T_LANELINE_LINEAR_REWARD) {  // reward.py:40-41
       for (int l = 0; l < C; l++) {
-        const double d = __shfl(dist_l, l);
+        const double d = d_readlane(dist_l, l);
         reward = reward + d_linear_reward(d, tw, T->per_layer[l], 0.0);
       }
     } else if (kind == TC_T_CTE_SPARSE_REWARD) {  // reward.py:60
@@ -120,13 +127,12 @@ __device__ __forceinline__ void d_apply_terms(const tc_term* terms, int n_terms,
       reward = reward + d_linear_reward(cte, T->p[0], T->p[1], T->p[2]);
     } else if (kind == TC_T_LANELINE_CROSSING_TERMINATION) {  // termination.py:19-21
       for (int l = 0; l < C; l++) {
-        const double d = __shfl(dist_l, l);
+        const double d = d_readlane(dist_l, l);
         if (((mask >> l) & 1u) && d <= half) terminated = 1;
       }
     } else if (kind == TC_T_CTE_TERMINATION || kind == TC_T_CRASH_TERMINATION) {  // termination.py:39-47,61-69
       const bool cond = kind == TC_T_CTE_TERMINATION ? (tc_fabs(cte) > T->p[0]) : (tc_fabs(vel) < T->p[0]);
-      int* cp = counters + (size_t)env * TC_MAX_TERMS + t;
-      int c = *cp;
+      int c = __builtin_amdgcn_readlane(my_cnt, t);
       if (cond) {
         c += 1;
         if (c >= T->number_of_steps) {
@@ -136,7 +142,7 @@ __device__ __forceinline__ void d_apply_terms(const tc_term* terms, int n_terms,
       } else {
         c = 0;
       }
-      if (tid == 0) *cp = c;
+      if (tid == t) my_cnt = c;
     }
   }
 }
@@ -322,6 +328,10 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
   s.lp_len = b.lp_len[env];
   s.last_maneuver = b.last_maneuver[env];
 
+  // steps_true of the consecutive-step terms: one coalesced 32-byte load now, hidden behind phase A
+  int my_cnt = 0;
+  if (a.n_terms > 0 && a.term_counters && tid < TC_MAX_TERMS) my_cnt = a.term_counters[(size_t)env * TC_MAX_TERMS + tid];
+
   int status = 0, trunc = 0;
   bool have_trig = false;  // s.cth / s.sth hold cos / sin of the current heading
   PathInfo pinfo;
@@ -474,9 +484,11 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     }
     if (late) {
       // a re-spawned env did not go through Wrapper.step (the reference's reset() bypasses the wrappers)
-      if (!fresh)
-        d_apply_terms(a.terms, a.n_terms, a.term_counters, a.car.track_width, env, tid, C, cte,
-                      have_info ? s.velocity : 0.0, dist_l, reward, terminated);
+      if (!fresh) {
+        d_apply_terms(a.terms, a.n_terms, my_cnt, a.car.track_width, tid, C, cte, have_info ? s.velocity : 0.0, dist_l,
+                      reward, terminated);
+        if (a.term_counters && tid < a.n_terms) a.term_counters[(size_t)env * TC_MAX_TERMS + tid] = my_cnt;
+      }
       if (tid == 0) {
         b.reward[env] = reward;
         b.terminated[env] = (unsigned char)terminated;
