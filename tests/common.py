@@ -17,8 +17,8 @@ CFG = {"simple_layout": "config_simple_layout.yaml", "knuffingen": "config_knuff
 _cache = {}
 
 
-# configs that are test inputs only (tests/golden/): the synthetic stress map of make_stress_map.py
-TEST_CFG = {"stress_graph": "config_stress_graph.yaml"}
+# configs that are test inputs only (tests/golden/): the synthetic maps of make_stress_map.py
+TEST_CFG = {"stress_graph": "config_stress_graph.yaml", "oneway": "config_oneway.yaml"}
 
 
 def load_cfg(map_name):

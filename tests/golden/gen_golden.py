@@ -85,6 +85,7 @@ EXTRA_MAPS = {
                                           "config_formula_student_track.yaml"),
     # a synthetic map of this repo (make_stress_map.py): json_path is relative to the config itself
     "stress_graph": os.path.join(OUT, "config_stress_graph.yaml"),
+    "oneway": os.path.join(OUT, "config_oneway.yaml"),
 }
 RESOLUTIONS = {"r64": [64, 64], "r128": [128, 128], "r480": [480, 640]}
 
@@ -93,7 +94,7 @@ def load(map_name):
     if map_name in EXTRA_MAPS:
         with open(EXTRA_MAPS[map_name]) as f:
             cfg = yaml.safe_load(f)
-        if map_name == "stress_graph":
+        if map_name in ("stress_graph", "oneway"):
             path = EXTRA_MAPS[map_name]
         else:
             path = os.path.join(REF, "examples", "x.yaml")  # json_path is relative to the reference's examples/
@@ -450,6 +451,55 @@ def camera_mats():
     return out
 
 
+def exception_cases(n, seed):
+    """States on the one-way map (make_stress_map.py) from which the reference's Car.step RAISES, with controls that
+    do not: outcome 0 = returned normally (truncated recorded), 1 = TypeError (U-turn without an edge inside +-30 deg,
+    car.py:143), 2 = ValueError (min() over neighbours that are all self-loops, layer.py:123)."""
+    cfg, m, car, cams = load("oneway")
+    rng = np.random.default_rng(seed)
+    lp = m.lanepath
+    rec = Rec()
+    while len(rec.d.get("v", [])) < n:
+        e = lp.edges[int(rng.integers(0, 5))]          # one of the five road edges (not the self-loops)
+        n0, n1 = lp.nodes[e[0]], lp.nodes[e[1]]
+        a = rng.uniform(0.0, 1.0)
+        th = clip_angle(rng.normal(0, 0.3))
+        px = n0[0] + a * (n1[0] - n0[0]) + rng.normal(0, 0.01)
+        py = n0[1] + a * (n1[1] - n0[1]) + rng.normal(0, 0.01)
+        car.position = [px - car.wheelbase * math.cos(th), py - car.wheelbase * math.sin(th)]
+        car.rotation = th
+        car.update_position_front()
+        car.velocity = float(rng.uniform(0.01, 0.1))
+        car.steering_angle = 0.0
+        car.radius = 0.0
+        car.local_path = [(int(e[0]), int(e[1]))]
+        car.last_maneuver = int(rng.integers(0, 4))
+        man = int(rng.integers(0, 4))
+        v = float(np.float32(rng.uniform(0.2, 1.0)))
+        s = float(np.float32(rng.uniform(-0.3, 0.3)))
+        pre = state_vec(car)
+        cc = clip_action(v, s)
+        outcome, trunc = 0, False
+        try:
+            trunc = car.step(cc[0], cc[1], man)
+        except TypeError as ex:
+            assert "subscriptable" in str(ex), ex
+            outcome = 1
+        except ValueError as ex:
+            assert "empty" in str(ex), ex
+            outcome = 2
+        rec.add(v=v, s=s, maneuver=man, outcome=outcome, truncated=bool(trunc),
+                **{"pre_" + k: v_ for k, v_ in pre.items()})
+    return rec.arrays()
+
+
+def main_exceptions():
+    out = exception_cases(600, 21)
+    np.savez_compressed(os.path.join(OUT, "exceptions_oneway.npz"), **out)
+    print("exceptions_oneway.npz outcomes [ok, TypeError, ValueError] =", np.bincount(out["outcome"], minlength=3).tolist(),
+          "ok-and-truncated", int((out["truncated"] & (out["outcome"] == 0)).sum()))
+
+
 def main_stress():
     """rollouts on the synthetic stress map: hub with 5 successors / predecessors, dead end, self-loops, duplicate and
     zero-length edges"""
@@ -611,6 +661,8 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         main_extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == "exceptions":
+        main_exceptions()
     elif len(sys.argv) > 1 and sys.argv[1] == "stress":
         main_stress()
     elif len(sys.argv) > 1 and sys.argv[1] == "wrappers":

@@ -87,3 +87,19 @@ for a, b in edges:
 print("lanepath nodes", len(nodes), "edges", len(edges), "hub", hub, "out", len(succ[hub]), "in", len(pred[hub]),
       "sinks", [i for i in range(len(nodes)) if i not in succ])
 print("spoke mid-points into the hub", [e[1] for e in spokes_in[0::2]], "out of the hub", [e[1] for e in spokes_out[0::2]])
+
+
+# ---- oneway.json: a straight one-way road whose last node has two self-loops and nothing else.
+# The reference RAISES on it in two documented ways (gen_golden.py `exceptions` records which states do):
+#   * U-turn (maneuver 2): no lanepath edge lies within +-30 deg of the reversed heading -> local_path = [None] ->
+#     TypeError at car.py:143;
+#   * look-ahead reaching node 5: get_next_nodes(5) == [5, 5], both filtered from the angle list -> min() of an empty
+#     range -> ValueError at layer.py:123.
+ow_nodes = [[100 + 90 * i, 300] for i in range(6)]
+ow_edges = [[i, i + 1] for i in range(5)] + [[5, 5], [5, 5]]
+ow_lines = {"left": {"layer_color": [255, 0, 0], "nodes": [[60, 270], [640, 270]], "edges": [[0, 1]]},
+            "right": {"layer_color": [0, 255, 0], "nodes": [[60, 330], [350, 330], [640, 330]], "edges": [[0, 1], [1, 2]]}}
+with open(os.path.join(OUT, "oneway.json"), "w") as f:
+    json.dump({"width": 700, "height": 600, "lanelines": ow_lines,
+               "lanepath": {"layer_color": [255, 255, 255], "nodes": ow_nodes, "edges": ow_edges}}, f)
+print("oneway: lanepath nodes", len(ow_nodes), "edges", len(ow_edges))

@@ -14,6 +14,7 @@ MAXC = 16
 MATH_LIBM, MATH_PORTABLE = 0, 1
 FMT_RGB, FMT_CLASSES = 0, 1
 F_NO_OBSERVATION, F_WRAPPED, F_AUTORESET, F_DEVICE_SPAWN = 1, 2, 4, 8
+S_UTURN_NO_EDGE, S_PICK_EMPTY = 1, 2  # ORC_S_* status bits
 
 
 class Car(C.Structure):

@@ -610,3 +610,27 @@ def test_knuffingen_kernel_variants_agree_with_oracle(groups, fuse, monkeypatch)
         assert (p["raster_us"] < 0.25 * p["simulate_us"]) == one_launch, p
         assert int(env.out["obs"].max()) > 0
         env.close()
+
+
+def test_reference_exceptions_become_status_bits_on_gpu():
+    """the states from which the reference raised (tests/golden/exceptions_oneway.npz): the kernel flags exactly the
+    same envs, with the same bits, as the oracle (itself checked against the recorded outcomes on the CPU side)"""
+    from tinycarlo_amd import _native as nat
+    d = golden("exceptions_oneway.npz")
+    T = len(d["v"])
+    env = make_env("oneway", "r64", "classes", T)
+    o = make_oracle(env)
+    pre = _states_from(d, "pre_")
+    o.state[:] = pre
+    push_state(env, pre)
+    cc = np.stack([d["v"], d["s"]], axis=1)
+    o.step(cc, d["maneuver"], flags=0)
+    env.step({"car_control": cc, "maneuver": d["maneuver"].astype(np.int32)})
+    assert_same(env, o, env.n_classes, label="exceptions")
+    st = env.out["status"].cpu().numpy()
+    oc = d["outcome"]
+    assert ((st[oc == 1] & 3) == nat.S_UTURN_NO_EDGE).all() and ((st[oc == 2] & 3) == nat.S_PICK_EMPTY).all()
+    assert ((st[oc == 0] & 3) == 0).all()
+    tr = env.out["truncated"].cpu().numpy().astype(bool)
+    assert tr[oc != 0].all() and np.array_equal(tr[oc == 0], d["truncated"][oc == 0].astype(bool))
+    env.close()

@@ -175,6 +175,30 @@ def test_single_steps(mp, mode, tol):
         orc.set_math_mode(orc.MATH_LIBM)
 
 
+@pytest.mark.parametrize("mode", [orc.MATH_LIBM, orc.MATH_PORTABLE])
+def test_reference_exceptions_become_status_bits(mode):
+    """exceptions_oneway.npz: states from which the reference's Car.step raised (TypeError at car.py:143 for a U-turn
+    with no edge inside +-30 deg; ValueError at layer.py:123 for min() over all-self-loop neighbours) and controls
+    from which it returned.  The oracle reports the former as truncated + the matching status bit and agrees with
+    the reference's `truncated` on the latter."""
+    d = golden("exceptions_oneway.npz")
+    _, m, car, cam = setup("oneway", "r64")
+    orc.set_math_mode(mode)
+    try:
+        T = len(d["v"])
+        o = orc.Oracle(m, car, cam, orc.FMT_CLASSES, T)
+        o.state[:] = _states_from(d, "pre_")
+        o.step(np.stack([d["v"], d["s"]], axis=1), d["maneuver"], flags=orc.F_WRAPPED, with_obs=False)
+        st, tr, oc = o.info["status"], o.info["truncated"].astype(bool), d["outcome"]
+        assert (oc == 1).sum() > 50 and (oc == 2).sum() > 50 and (oc == 0).sum() > 50
+        assert ((st[oc == 1] & 3) == orc.S_UTURN_NO_EDGE).all() and tr[oc == 1].all()
+        assert ((st[oc == 2] & 3) == orc.S_PICK_EMPTY).all() and tr[oc == 2].all()
+        assert ((st[oc == 0] & 3) == 0).all()
+        assert np.array_equal(tr[oc == 0], d["truncated"][oc == 0].astype(bool))
+    finally:
+        orc.set_math_mode(orc.MATH_LIBM)
+
+
 # ------------------------------------------------------------------ the reference's unit tests as vectors
 @pytest.fixture(scope="module")
 def uv():
