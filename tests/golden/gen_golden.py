@@ -451,6 +451,67 @@ def camera_mats():
     return out
 
 
+# camera parameter sets of the sweep: (pitch, roll, yaw, fov, position, max_range, resolution, thickness).
+# The first six follow examples/train_stanley_il.py:53-57 (pitch in [10, 20), fov in [90, 130), set on the live
+# camera object followed by update_params()); the rest vary what no example varies.
+def sweep_sets():
+    rng = np.random.default_rng(99)
+    sets = []
+    for _ in range(6):
+        sets.append(dict(orientation=[int(rng.integers(10, 20)), 0, 0], fov=int(rng.integers(90, 130)),
+                         position=[0.0, -0.005, 0.04], max_range=0.5, resolution=[64, 64], line_thickness=2))
+    base = dict(orientation=[22, 0, 0], fov=80, position=[0.0, -0.005, 0.04], max_range=0.5, resolution=[64, 64],
+                line_thickness=2)
+    for over in [dict(orientation=[22, 5, 0]), dict(orientation=[22, 0, 15]), dict(orientation=[15, -8, -20]),
+                 dict(orientation=[0, 0, 0]), dict(orientation=[45, 0, 0]), dict(orientation=[80, 0, 90]),
+                 dict(orientation=[-10, 0, 0]), dict(position=[0.02, 0.01, 0.06]), dict(position=[-0.03, 0.0, 0.1]),
+                 dict(max_range=0.3), dict(max_range=1.0), dict(max_range=2.5, fov=60),
+                 dict(resolution=[128, 160], line_thickness=3), dict(resolution=[48, 96], fov=110, orientation=[12, 3, -4])]:
+        sets.append({**base, **over})
+    return sets
+
+
+def camera_sweep():
+    """Reference E / K and the segment lists handed to cv2.polylines for 20 camera parameter sets x 16 car states per
+    map.  orientation / fov are changed on the constructed camera and applied with update_params() (camera.py:48-50),
+    the way the IL trainer randomises them; position / max_range / resolution go through the constructor."""
+    out = {"sets": sweep_sets(), "maps": {}}
+    arrays = {}
+    for mn, src in [("simple_layout", "rollout_simple_layout_random_0.npz"), ("knuffingen", "rollout_knuffingen_stanley_1.npz")]:
+        cfg, m, car, _ = load(mn)
+        ren = Renderer.__new__(Renderer)
+        d = np.load(os.path.join(OUT, src))
+        idx = list(range(5, len(d["v"]), max(1, len(d["v"]) // 16)))[:16]
+        out["maps"][mn] = {"rollout": src, "steps": idx}
+        Es, Ks, segs_i, segs_f = [], [], [], []
+        for ps in out["sets"]:
+            cc = dict(cfg["camera"])
+            cc.update(position=list(ps["position"]), max_range=ps["max_range"], resolution=list(ps["resolution"]),
+                      line_thickness=ps["line_thickness"])
+            cam = Camera(m, car, ren, cc)            # built with the config's orientation / fov ...
+            cam.orientation = list(ps["orientation"])  # ... then randomised like train_stanley_il.py:55-57
+            cam.fov = ps["fov"]
+            cam.update_params()
+            Es.append(np.array(cam.E))
+            Ks.append(np.array(cam.K))
+            for t in idx:
+                car.position = [float(d["post_x"][t]), float(d["post_y"][t])]
+                car.rotation = float(d["post_theta"][t])
+                car.update_position_front()
+                si, sf = capture(cam)
+                segs_i.append(si)
+                segs_f.append(sf)
+        arrays[f"{mn}_E"] = np.array(Es)
+        arrays[f"{mn}_K"] = np.array(Ks)
+        arrays[f"{mn}_seg"], arrays[f"{mn}_seg_off"] = ragged(segs_i, 5, np.int32)
+        arrays[f"{mn}_segf"], _ = ragged(segs_f, 4, np.float64)
+        print(mn, "sets", len(out["sets"]), "states", len(idx), "segments", len(arrays[f"{mn}_seg"]),
+              "frames without any", int(sum(len(x) == 0 for x in segs_i)))
+    with open(os.path.join(OUT, "camera_sweep.json"), "w") as f:
+        json.dump(out, f)
+    np.savez_compressed(os.path.join(OUT, "camera_sweep.npz"), **arrays)
+
+
 def exception_cases(n, seed):
     """States on the one-way map (make_stress_map.py) from which the reference's Car.step RAISES, with controls that
     do not: outcome 0 = returned normally (truncated recorded), 1 = TypeError (U-turn without an edge inside +-30 deg,
@@ -661,6 +722,8 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         main_extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cameras":
+        camera_sweep()
     elif len(sys.argv) > 1 and sys.argv[1] == "exceptions":
         main_exceptions()
     elif len(sys.argv) > 1 and sys.argv[1] == "stress":

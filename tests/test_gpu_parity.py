@@ -634,3 +634,72 @@ def test_reference_exceptions_become_status_bits_on_gpu():
     tr = env.out["truncated"].cpu().numpy().astype(bool)
     assert tr[oc != 0].all() and np.array_equal(tr[oc == 0], d["truncated"][oc == 0].astype(bool))
     env.close()
+
+
+def _oracle_frames(o):
+    """renderer.py:36-51 of the oracle's current states into o.obs (no step)"""
+    import ctypes as C
+    for i in range(o.n):
+        seg, _ = o.segments(i)
+        seg = np.ascontiguousarray(seg)
+        orc.lib().orc_render(o.map.h, C.byref(o.cam), orc._ip(seg) if len(seg) else None, len(seg), orc._bp(o.obs[i]))
+
+
+@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen"])
+def test_camera_sweep_frames(mp):
+    """The 20 camera parameter sets of tests/golden/camera_sweep.* (their E / K and segment lists are pinned to the
+    reference on the CPU side) on the GPU: every set through the shared-camera path (tc_env_set_camera via
+    Camera.update_params), and the sets that share resolution / range / thickness again in ONE batch through the
+    per-env path (tc_env_set_camera_per_env) -- frames identical to the oracle's."""
+    import json
+    import os
+    from common import GOLDEN
+    with open(os.path.join(GOLDEN, "camera_sweep.json")) as f:
+        meta = json.load(f)
+    src = golden(meta["maps"][mp]["rollout"])
+    steps = meta["maps"][mp]["steps"]
+    post = _states_from(src, "post_")[steps]
+    S = len(steps)
+    lit = 0
+    for pi, ps in enumerate(meta["sets"]):
+        cam_cfg = dict(position=list(ps["position"]), max_range=ps["max_range"], line_thickness=ps["line_thickness"])
+        from common import RES
+        RES["sweep"] = list(ps["resolution"])
+        env = make_env(mp, "sweep", "classes", S, camera=cam_cfg)
+        env.camera.orientation = list(ps["orientation"])   # train_stanley_il.py:55-57
+        env.camera.fov = ps["fov"]
+        env.camera.update_params()
+        o = make_oracle(env)
+        o.state[:] = post
+        push_state(env, post)
+        env.render_current()
+        _oracle_frames(o)
+        torch.cuda.synchronize()
+        g = env.out["obs"].cpu().numpy().reshape(S, -1)
+        assert np.array_equal(g, o.obs), (mp, pi, ps)
+        lit += int((g != 0).sum())
+        env.close()
+    assert lit > 10000
+    # per-env: all sets with the default resolution / range / thickness in one batch
+    base = [ps for ps in meta["sets"] if ps["resolution"] == [64, 64] and ps["max_range"] == 0.5 and ps["line_thickness"] == 2]
+    assert len(base) >= 12
+    N = len(base) * S
+    env = make_env(mp, "r64", "classes", N)
+    ori = np.repeat(np.array([ps["orientation"] for ps in base], dtype=np.float64), S, axis=0)
+    fov = np.repeat(np.array([ps["fov"] for ps in base], dtype=np.float64), S)
+    pos = np.repeat(np.array([ps["position"] for ps in base], dtype=np.float64), S, axis=0)
+    env.set_env_cameras(orientation=ori, fov=fov, position=pos)
+    st = np.tile(post, len(base))
+    push_state(env, st)
+    env.render_current()
+    torch.cuda.synchronize()
+    g = env.out["obs"].cpu().numpy().reshape(N, -1)
+    for bi, ps in enumerate(base):
+        cfg_cam = copy.deepcopy(env.config["camera"])
+        cfg_cam.update(orientation=list(ps["orientation"]), fov=ps["fov"], position=list(ps["position"]))
+        from tinycarlo_amd.camera import Camera
+        o = orc.Oracle(env.map, env.car_params, Camera(cfg_cam), orc.FMT_CLASSES, S)
+        o.state[:] = post
+        _oracle_frames(o)
+        assert np.array_equal(g[bi * S:(bi + 1) * S], o.obs), (mp, "per-env", bi, ps)
+    env.close()

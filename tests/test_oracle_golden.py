@@ -17,7 +17,8 @@ import numpy as np
 import pytest
 
 import orc
-from common import GOLDEN, cam_keys, golden, map_of, rollout_files, setup
+from tinycarlo_amd.camera import Camera
+from common import GOLDEN, cam_keys, golden, load_cfg, map_of, rollout_files, setup
 
 FTOL = 1e-12
 
@@ -260,3 +261,51 @@ def test_camera_matrices():
         _, _, _, cam = setup(mp, rk)
         assert np.array_equal(cam.E, np.array(v["E"])), key
         assert np.array_equal(cam.K, np.array(v["K"])), key
+
+
+# ------------------------------------------------------------------ camera parameter sweep (camera.py:48-50,145-178)
+def _sweep():
+    with open(os.path.join(GOLDEN, "camera_sweep.json")) as f:
+        meta = json.load(f)
+    return meta, golden("camera_sweep.npz")
+
+
+def sweep_camera(mp, ps):
+    """the host mirror driven the way examples/train_stanley_il.py:53-57 drives the reference's camera: built from the
+    config, orientation / fov changed on the object, update_params()"""
+    cfg, _ = load_cfg(mp)
+    cc = dict(cfg["camera"])
+    cc.update(position=list(ps["position"]), max_range=ps["max_range"], resolution=list(ps["resolution"]),
+              line_thickness=ps["line_thickness"])
+    cam = Camera(cc)
+    cam.orientation = list(ps["orientation"])
+    cam.fov = ps["fov"]
+    cam.update_params()
+    return cam
+
+
+@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen"])
+def test_camera_sweep_matrices_and_segments(mp):
+    """20 camera parameter sets (the IL trainer's pitch / fov ranges, roll and yaw, other mounting positions, ranges
+    and resolutions) x 16 car states: E and K of the host mirror equal the reference's bit for bit, and the oracle
+    hands the same int32 segments to the rasteriser as the reference hands to cv2.polylines."""
+    meta, d = _sweep()
+    _, m, car, _ = setup(mp, "r64")
+    src = golden(meta["maps"][mp]["rollout"])
+    steps = meta["maps"][mp]["steps"]
+    post = _states_from(src, "post_")[steps]
+    off = d[f"{mp}_seg_off"]
+    k = 0
+    drawn = 0
+    for pi, ps in enumerate(meta["sets"]):
+        cam = sweep_camera(mp, ps)
+        assert np.array_equal(cam.E, d[f"{mp}_E"][pi]), (pi, ps)
+        assert np.array_equal(cam.K, d[f"{mp}_K"][pi]), (pi, ps)
+        o = orc.Oracle(m, car, cam, orc.FMT_CLASSES, len(steps))
+        o.state[:] = post
+        for si in range(len(steps)):
+            seg = d[f"{mp}_seg"][off[k]:off[k + 1]]
+            _check_segments(o, seg, d[f"{mp}_segf"][off[k]:off[k + 1]], (mp, pi, si), i=si)
+            drawn += len(seg)
+            k += 1
+    assert k == len(off) - 1 and drawn > 1000
