@@ -703,3 +703,26 @@ def test_camera_sweep_frames(mp):
         _oracle_frames(o)
         assert np.array_equal(g[bi * S:(bi + 1) * S], o.obs), (mp, "per-env", bi, ps)
     env.close()
+
+
+@pytest.mark.parametrize("N", [1, 3, 65, 65536])
+def test_batch_sizes(N):
+    """one env, odd counts, and 16x the benchmark's batch (many dispatch rounds, 64-bit buffer offsets): same bits as
+    the oracle for state, info and frames"""
+    env = make_env("simple_layout", "r64", "classes", N, autoreset=True, spawn_queue_len=2)
+    o = make_oracle(env, threads=16)
+    rng = np.random.default_rng(N)
+    spawn = env.map.spawn_table()
+    nodes = spawn[rng.integers(0, len(spawn), N)].astype(np.int32)
+    env._aux["spawn_queue"].copy_(torch.from_numpy(spawn[rng.integers(0, len(spawn), (N, 2))].astype(np.int32)))
+    env.reset_to(nodes)
+    o.spawn_queue = env._aux["spawn_queue"].cpu().numpy()
+    o.reset(nodes)
+    steps = 6 if N > 1000 else 40
+    for t in range(steps):
+        cc = np.stack([rng.uniform(0.2, 1.0, N), rng.uniform(-1, 1, N)], axis=1)
+        man = rng.integers(0, 4, N).astype(np.int32)
+        o.step(cc, man, flags=orc.F_AUTORESET)
+        env.step({"car_control": cc, "maneuver": man})
+        assert_same(env, o, env.n_classes, check_obs=(t == steps - 1), label=f"N={N} step {t}")
+    env.close()
