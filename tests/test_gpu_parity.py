@@ -726,3 +726,24 @@ def test_batch_sizes(N):
         env.step({"car_control": cc, "maneuver": man})
         assert_same(env, o, env.n_classes, check_obs=(t == steps - 1), label=f"N={N} step {t}")
     env.close()
+
+
+def test_reset_to_with_device_mask():
+    """TinyCarloVecEnv.reset_to(mask=<cuda bool / uint8 tensor>): only the selected envs are re-spawned"""
+    env = make_env("simple_layout", "r64", "classes", 8)
+    env.reset(seed=0)
+    torch.cuda.synchronize()
+    before = env.state["x"].clone()
+    node = int(env.map.spawn_table()[5])
+    nodes = torch.full((8,), node, dtype=torch.int32, device="cuda:0")
+    for mk in (torch.tensor([1, 0, 1, 0, 0, 0, 0, 1], dtype=torch.bool, device="cuda:0"),
+               torch.tensor([1, 0, 1, 0, 0, 0, 0, 1], dtype=torch.uint8, device="cuda:0")):
+        env.state["x"].copy_(before)
+        env.state["local_path"].fill_(0)
+        env.reset_to(nodes, mask=mk)
+        torch.cuda.synchronize()
+        sel = mk.bool().cpu().numpy()
+        lp0 = env.state["local_path"][:, 0].cpu().numpy()
+        assert (lp0[sel] == node).all() and (lp0[~sel] == 0).all()
+        assert torch.equal(env.state["x"][~mk.bool()], before[~mk.bool()])
+    env.close()

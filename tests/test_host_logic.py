@@ -259,3 +259,17 @@ def test_cte_termination_counter_semantics():
     wb = CTETerminationWrapper(FakeB([0.5, 0.5, 0.0, 0.5, 0.5, 0.5, 0.5]), 0.1, number_of_steps=3)
     gb = [wb.step(None)[2].tolist() for _ in range(7)]
     assert [g[0] for g in gb] == got and [g[1] for g in gb] == [False, False, True, False, False, True, False]
+
+
+def test_reset_to_accepts_tensor_masks():
+    """reset_to(mask=...) with a torch bool / uint8 tensor (the form a device-side RL loop has) as well as numpy"""
+    e = OracleVecEnv(cfg_for("simple_layout"), num_envs=4)
+    e.reset(seed=0)
+    before = {k: v.clone() for k, v in e.state.items()}
+    nodes = np.array([e.map.spawn_table()[3]] * 4, dtype=np.int32)
+    for mk in (torch.tensor([True, False, False, True]), torch.tensor([1, 0, 0, 1], dtype=torch.uint8), np.array([1, 0, 0, 1])):
+        for k, v in before.items():
+            e.state[k].copy_(v)
+        e.reset_to(nodes, mask=mk)
+        assert e.state["local_path"][:, 0].tolist()[0] == int(nodes[0]) == e.state["local_path"][:, 0].tolist()[3]
+        assert torch.equal(e.state["x"][1:3], before["x"][1:3])

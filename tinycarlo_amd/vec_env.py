@@ -299,7 +299,12 @@ class TinyCarloVecEnv(gym.Env):
     def reset_to(self, spawn_nodes, mask=None) -> None:
         """Reset with explicit spawn nodes (lanepath node ids); device-side only, no RNG involved."""
         nd = self._to_dev("spawn_nodes", spawn_nodes, torch.int32, (self.num_envs,))
-        mk = None if mask is None else self._to_dev("mask", np.asarray(mask, dtype=np.uint8), torch.uint8, (self.num_envs,))
+        if mask is None:
+            mk = None
+        elif isinstance(mask, torch.Tensor):  # bool / uint8 tensors (host or device) are taken as they are
+            mk = self._to_dev("mask", mask.to(torch.uint8), torch.uint8, (self.num_envs,))
+        else:
+            mk = self._to_dev("mask", np.asarray(mask, dtype=np.uint8), torch.uint8, (self.num_envs,))
         with torch.cuda.device(self.device):
             nat.check(nat.lib().tc_reset(self._h, nd.data_ptr(), mk.data_ptr() if mk is not None else None,
                                          self._flags() & ~nat.F_AUTORESET, self._stream()), "tc_reset")
