@@ -189,6 +189,17 @@ int tc_env_set_terms(tc_env* env, const tc_term* terms, int32_t n_terms, int32_t
  * Re-spawn number k of env i uses SplitMix64 output (i << 32 | k) of the stream `seed`.  Not seed-compatible with
  * the reference's numpy generator; the host-drawn spawn_queue remains the seed-parity mode.  n = 0 removes the table. */
 int tc_env_set_spawn_table(tc_env* env, const int32_t* nodes, int32_t n, uint64_t seed);
+/* NoiseObservationWrapper (wrapper/observation.py:5-33) for class-mask observations: per class plane n_blobs blobs,
+ * each a filled circle (centre inside the frame, radius in [1, max_radius)) that either erases the plane inside the
+ * circle or ORs in the circle-masked content of a random plane, applied in order.  With n_blobs > 0 every tc_step
+ * that renders an observation is followed by the noise kernel on the same stream, blobs drawn on the device
+ * (tinycarlo_amd/csrc/tc_rng.h; the reference draws from the global numpy generator, which cannot be reproduced
+ * for a batch).  n_blobs = 0 switches it off.  Needs TC_FMT_CLASSES and max_radius in [2, 256]. */
+int tc_env_set_noise(tc_env* env, int32_t n_blobs, int32_t max_radius, uint64_t seed);
+/* The noise pass alone, on the currently bound observation.  blobs: device int32 [N][n_layers * n_blobs][5] rows
+ * (x, y, radius, mode, src) -- blob k belongs to plane k / n_blobs, mode 1 = copy from plane src, 0 = erase -- or
+ * NULL to draw them on the device as tc_step does. */
+int tc_noise(tc_env* env, const int32_t* blobs, void* stream);
 /* bytes of one env's observation */
 int64_t tc_env_obs_bytes(const tc_env* env);
 /* dynamic LDS bytes one workgroup of the step kernel uses (for occupancy reporting) */

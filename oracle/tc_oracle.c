@@ -1031,6 +1031,42 @@ void orc_step_batch_terms(const orc_map* m, const orc_car* c, const orc_cam* cam
                      spawn_queue_len, spawn_cursor, n_threads, &ext);
 }
 
+void orc_noise_classes(uint8_t* frame, int C, int H, int W, const int32_t* blobs, int n_blobs) {
+  uint8_t* mask = (uint8_t*)malloc((size_t)H * W);
+  for (int k = 0; k < C * n_blobs; k++) {
+    const int c = k / n_blobs; /* observation.py:16-17: planes outer, blobs inner */
+    const int x = blobs[5 * k], y = blobs[5 * k + 1], radius = blobs[5 * k + 2], mode = blobs[5 * k + 3],
+              src = blobs[5 * k + 4];
+    uint8_t* plane = frame + (size_t)c * H * W;
+    if (mode) { /* observation.py:21-24 */
+      img_t im = {mask, W, H, 1, {255, 255, 255}};
+      memset(mask, 0, (size_t)H * W);
+      circle_fill(&im, x, y, radius);
+      const uint8_t* other = frame + (size_t)src * H * W;
+      for (size_t i = 0; i < (size_t)H * W; i++) {
+        uint8_t m = mask[i] ? (uint8_t)(other[i] & mask[i]) : 0; /* bitwise_and(src1, mask, mask=mask) */
+        plane[i] = plane[i] | m;                                   /* bitwise_or */
+      }
+    } else { /* observation.py:26 */
+      img_t im = {plane, W, H, 1, {0, 0, 0}};
+      circle_fill(&im, x, y, radius);
+    }
+  }
+  free(mask);
+}
+
+void orc_noise_blobs(uint64_t seed, uint32_t env, uint32_t step, int n_blobs, int C, int H, int W, int max_radius,
+                     int32_t* out) {
+  for (int k = 0; k < C * n_blobs; k++) {
+    tc_blob b = tc_noise_blob(seed, env, step, (uint32_t)k, W, H, max_radius, C);
+    out[5 * k] = b.x;
+    out[5 * k + 1] = b.y;
+    out[5 * k + 2] = b.r;
+    out[5 * k + 3] = b.mode;
+    out[5 * k + 4] = b.src;
+  }
+}
+
 uint64_t orc_splitmix64_at(uint64_t seed, uint64_t n) { return tc_splitmix64_at(seed, n); }
 uint32_t orc_spawn_index(uint64_t seed, uint32_t env, uint32_t cursor, uint32_t count) {
   return tc_spawn_index(seed, env, cursor, count);

@@ -168,6 +168,14 @@ void orc_step_batch_ext(const orc_map*, const orc_car*, const orc_cam*, int N, o
                         const int32_t* maneuver, uint32_t flags, orc_info* info, uint8_t* obs, uint8_t* needs_reset,
                         const int32_t* spawn_queue, int spawn_queue_len, int32_t* spawn_cursor, int n_threads,
                         const orc_step_ext* ext);
+/* wrapper/observation.py:15-27 (add_blob_noise_classes) on one class-mask frame [C][H][W] with the random draws given:
+ * blobs [C * n_blobs][5] rows (x, y, radius, mode, src); blob k belongs to plane k / n_blobs; mode 1 = the "True"
+ * branch (copy the circle-masked content of plane src in), 0 = erase the circle.  cv2.circle is this file's
+ * restatement of Circle(..., fill) -- pixels unpinned like the rest of the raster. */
+void orc_noise_classes(uint8_t* frame, int C, int H, int W, const int32_t* blobs, int n_blobs);
+/* the blobs the device draws for (env, step): tinycarlo_amd/csrc/tc_rng.h (no reference counterpart) */
+void orc_noise_blobs(uint64_t seed, uint32_t env, uint32_t step, int n_blobs, int C, int H, int W, int max_radius,
+                     int32_t* out);
 /* tinycarlo_amd/csrc/tc_rng.h, exported for the known-answer tests */
 uint64_t orc_splitmix64_at(uint64_t seed, uint64_t n);
 uint32_t orc_spawn_index(uint64_t seed, uint32_t env, uint32_t cursor, uint32_t count);

@@ -512,6 +512,88 @@ def camera_sweep():
     np.savez_compressed(os.path.join(OUT, "camera_sweep.npz"), **arrays)
 
 
+def noise_draws():
+    """The order in which NoiseObservationWrapper.add_blob_noise_classes (wrapper/observation.py:15-27) consumes the
+    global numpy generator.  cv2 is a recording stand-in (circle / bitwise_and / bitwise_or do nothing): the pixel
+    operations do not influence the draws, and the pixels themselves cannot be pinned without OpenCV."""
+    import tinycarlo.wrapper.observation as ob   # needs the gymnasium stand-in of main_wrappers()
+    rec = []
+
+    def circle(img, center, radius, color, thickness):
+        assert thickness == -1
+        rec.append(["circle", int(center[0]), int(center[1]), int(radius), int(color)])
+        return img
+
+    def bitwise_and(a, b, mask=None):
+        rec.append(["and"])
+        return np.zeros_like(b)
+
+    def bitwise_or(a, b):
+        rec.append(["or"])
+        return a
+
+    cv2.circle, cv2.bitwise_and, cv2.bitwise_or = circle, bitwise_and, bitwise_or
+
+    class Stub:
+        wrapped = False
+
+        @property
+        def unwrapped(self):
+            return self
+
+    out = []
+    for seed, (C_, H, W), n_blobs, max_r in [(123, (5, 64, 64), 10, 100), (7, (3, 48, 96), 4, 20), (99, (5, 128, 128), 10, 100)]:
+        rec.clear()
+        w = ob.NoiseObservationWrapper(Stub(), blob_max_radius=max_r, n_blobs=n_blobs)
+        obs = np.zeros((C_, H, W), dtype=np.uint8)
+        # which plane index is read on the copy branch: observation[np.random.randint(0, C)] -> wrap the array
+        reads = []
+
+        class Spy:
+            shape = obs.shape
+
+            def __getitem__(self, i):
+                reads.append(int(i))
+                return obs[i]
+
+            def __setitem__(self, i, v):
+                reads.append(("set", int(i)))
+
+        np.random.seed(seed)
+        w.add_blob_noise_classes(Spy())
+        # rebuild (x, y, radius, mode, src) rows from the recorded calls
+        rows, ri = [], 0
+        k = 0
+        while k < len(rec):
+            _, x, y, r, color = rec[k]
+            if color == 255:   # copy branch: circle(mask) , observation[src] read, bitwise_and, bitwise_or
+                assert rec[k + 1] == ["and"] and rec[k + 2] == ["or"]
+                rows.append([x, y, r, 1, None])
+                k += 3
+            else:
+                rows.append([x, y, r, 0, -1])
+                k += 1
+        # plane reads on the copy branch, in order: observation[c] (mask shape), observation[src], observation[c] (or)
+        it = iter(reads)
+        seq = [v for v in reads]
+        pos = 0
+        for bi, row in enumerate(rows):
+            c = bi // n_blobs
+            if row[3] == 1:
+                assert seq[pos] == c, (seq[pos:pos + 5], c)            # observation[c].shape
+                row[4] = seq[pos + 1]                                    # observation[randint]
+                assert seq[pos + 2] == c and seq[pos + 3] == ("set", c)  # bitwise_or(observation[c], ...) -> observation[c] =
+                pos += 4
+            else:
+                assert seq[pos] == c                                     # cv2.circle(observation[c], ...)
+                pos += 1
+        assert pos == len(seq) and len(rows) == C_ * n_blobs
+        out.append({"seed": seed, "shape": [C_, H, W], "n_blobs": n_blobs, "max_radius": max_r, "rows": rows})
+        print("noise draws seed", seed, "rows", len(rows), "copy branches", sum(r[3] for r in rows))
+    with open(os.path.join(OUT, "noise_draws.json"), "w") as f:
+        json.dump(out, f)
+
+
 def exception_cases(n, seed):
     """States on the one-way map (make_stress_map.py) from which the reference's Car.step RAISES, with controls that
     do not: outcome 0 = returned normally (truncated recorded), 1 = TypeError (U-turn without an edge inside +-30 deg,
@@ -614,10 +696,9 @@ def wrapper_stack(which, names):
             ("CTESparseRewardWrapper", dict(min_cte=0.02, sparse_reward=0.3))]
 
 
-def main_wrappers():
-    """The reference's wrapper classes (tinycarlo/wrapper/reward.py, termination.py) stacked on a replay env that
-    returns the info dicts of already recorded rollouts.  gymnasium is absent: `Wrapper` is stood in by the
-    minimal delegating class below (env / unwrapped / step), which is all the wrappers use."""
+def install_gymnasium_stub():
+    """gymnasium is absent: `Wrapper` is stood in by a minimal delegating class (env / unwrapped / step), which is
+    all the reference's wrappers use"""
     g = types.ModuleType("gymnasium")
 
     class Env:
@@ -638,6 +719,14 @@ def main_wrappers():
 
     g.Env, g.Wrapper = Env, Wrapper
     sys.modules["gymnasium"] = g
+    return Env, Wrapper
+
+
+def main_wrappers():
+    """The reference's wrapper classes (tinycarlo/wrapper/reward.py, termination.py) stacked on a replay env that
+    returns the info dicts of already recorded rollouts.  gymnasium is absent: `Wrapper` is stood in by the
+    minimal delegating class below (env / unwrapped / step), which is all the wrappers use."""
+    Env, Wrapper = install_gymnasium_stub()
     import tinycarlo.wrapper.reward as rw
     import tinycarlo.wrapper.termination as tm
     from tinycarlo.wrapper.utils import linear_reward, sparse_reward
@@ -722,6 +811,9 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         main_extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == "noise":
+        install_gymnasium_stub()
+        noise_draws()
     elif len(sys.argv) > 1 and sys.argv[1] == "cameras":
         camera_sweep()
     elif len(sys.argv) > 1 and sys.argv[1] == "exceptions":

@@ -85,6 +85,24 @@ class OracleVecEnv(TinyCarloVecEnv):
         return (orc.F_NO_OBSERVATION if f & nat.F_NO_OBSERVATION else 0) | (orc.F_WRAPPED if f & nat.F_WRAPPED else 0) | \
                (orc.F_AUTORESET if f & nat.F_AUTORESET else 0) | (orc.F_DEVICE_SPAWN if f & nat.F_DEVICE_SPAWN else 0)
 
+    def _push_noise(self, n_blobs, max_radius, seed):
+        self._noise_step = 0
+
+    def _apply_noise(self, blobs=None):
+        n_blobs, max_radius, seed = self.noise
+        C, H, W = self._obs_shape
+        obs = self._o.obs.reshape((self.num_envs, C, H, W))
+        for i in range(self.num_envs):
+            b = blobs[i] if blobs is not None else orc.noise_blobs(seed, i, self._noise_step, n_blobs, C, H, W, max_radius)
+            orc.noise_classes(obs[i], b, n_blobs)
+        if blobs is None:
+            self._noise_step += 1
+        self.out["obs"].copy_(torch.from_numpy(obs.copy()))
+
+    def apply_noise(self, blobs=None):
+        self._apply_noise(None if blobs is None else np.asarray(blobs, dtype=np.int32))
+        return self.out["obs"]
+
     def _push_spawn_table(self, tab, seed):
         self._o.spawn_table, self._o.spawn_seed = np.array(tab, dtype=np.int32), seed
 
@@ -112,6 +130,8 @@ class OracleVecEnv(TinyCarloVecEnv):
         self._o.step(car_control.double().numpy(), maneuver.numpy(), flags=self._oflags(), with_obs=not no_obs)
         self._pull(with_obs=not no_obs)
         self._rerender_env_cams()
+        if self.noise[0] and not no_obs:
+            self._apply_noise()
 
     def render_current(self):
         self._push()

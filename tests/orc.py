@@ -99,6 +99,8 @@ def lib():
         L.orc_splitmix64_at.argtypes = [C.c_uint64, C.c_uint64]
         L.orc_spawn_index.restype = C.c_uint32
         L.orc_spawn_index.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_noise_classes.argtypes = [bp, C.c_int, C.c_int, C.c_int, ip, C.c_int]
+        L.orc_noise_blobs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip]
         L.orc_apply_terms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, ip]
         L.orc_linear_reward.restype = C.c_double
         L.orc_linear_reward.argtypes = [C.c_double] * 4
@@ -261,3 +263,18 @@ def polyline(img: np.ndarray, p0, p1, color, thickness: int):
     lib().orc_polyline2(_bp(img), img.shape[1], img.shape[0], ch, int(p0[0]), int(p0[1]), int(p1[0]), int(p1[1]),
                         _bp(col), thickness)
     return img
+
+
+def noise_classes(frame: np.ndarray, blobs: np.ndarray, n_blobs: int) -> np.ndarray:
+    """orc_noise_classes on a [C, H, W] uint8 frame (in place) with int32 blobs [C * n_blobs, 5]"""
+    assert frame.dtype == np.uint8 and frame.flags.c_contiguous and frame.ndim == 3
+    b = np.ascontiguousarray(blobs, dtype=np.int32).reshape(-1, 5)
+    assert len(b) == frame.shape[0] * n_blobs
+    lib().orc_noise_classes(_bp(frame), frame.shape[0], frame.shape[1], frame.shape[2], _ip(b), n_blobs)
+    return frame
+
+
+def noise_blobs(seed: int, env: int, step: int, n_blobs: int, C_: int, H: int, W: int, max_radius: int) -> np.ndarray:
+    out = np.zeros((C_ * n_blobs, 5), dtype=np.int32)
+    lib().orc_noise_blobs(seed, env, step, n_blobs, C_, H, W, max_radius, _ip(out))
+    return out

@@ -25,7 +25,7 @@ F_NO_OBSERVATION, F_WRAPPED, F_AUTORESET, F_DEVICE_SPAWN = 1, 2, 4, 8
 S_UTURN_NO_EDGE, S_PICK_EMPTY, S_BAD_SPAWN, S_NOT_RESET = 1, 2, 4, 8
 
 EXPORTS = ["tc_abi_version", "tc_last_error", "tc_map_create", "tc_map_destroy", "tc_env_create", "tc_env_destroy",
-           "tc_env_bind", "tc_env_set_camera", "tc_env_set_camera_per_env", "tc_env_set_terms", "tc_env_set_spawn_table", "tc_env_obs_bytes", "tc_env_lds_bytes", "tc_env_profile",
+           "tc_env_bind", "tc_env_set_camera", "tc_env_set_camera_per_env", "tc_env_set_terms", "tc_env_set_spawn_table", "tc_env_set_noise", "tc_noise", "tc_env_obs_bytes", "tc_env_lds_bytes", "tc_env_profile",
            "tc_env_profile_read", "tc_reset", "tc_step", "tc_render", "tc_render_segments"]
 
 _dp, _ip, _bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
@@ -108,6 +108,8 @@ def lib():
     L.tc_env_set_camera_per_env.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.tc_env_set_terms.argtypes = [C.c_void_p, C.POINTER(TermC), C.c_int32, C.c_void_p]
     L.tc_env_set_spawn_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64]
+    L.tc_env_set_noise.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64]
+    L.tc_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.tc_env_obs_bytes.restype = C.c_int64
     L.tc_env_obs_bytes.argtypes = [C.c_void_p]
     L.tc_env_lds_bytes.restype = C.c_int64

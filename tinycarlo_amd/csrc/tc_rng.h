@@ -27,4 +27,26 @@ TC_HD uint32_t tc_spawn_index(uint64_t seed, uint32_t env, uint32_t cursor, uint
   uint64_t z = tc_splitmix64_at(seed, ((uint64_t)env << 32) | cursor);
   return (uint32_t)(((z >> 32) * (uint64_t)count) >> 32);
 }
+
+// One blob of NoiseObservationWrapper (wrapper/observation.py:18-20): centre (x, y) inside the frame, radius in
+// [1, max_radius), mode 1 = "copy in" with probability 0.3 (else erase), src = the plane copied from.  Blob k of
+// (env, step) takes two outputs of the sub-stream SplitMix64(seed)[env << 32 | step].  The reference draws these
+// from the global numpy generator; this is the device-side stand-in with the same distributions (src and mode from
+// 8 and 24 bits).
+typedef struct {
+  int32_t x, y, r, mode, src;
+} tc_blob;
+
+TC_HD tc_blob tc_noise_blob(uint64_t seed, uint32_t env, uint32_t step, uint32_t k, int W, int H, int max_radius,
+                            int C) {
+  const uint64_t base = tc_splitmix64_at(seed, ((uint64_t)env << 32) | step);
+  const uint64_t a = tc_splitmix64_at(base, 2ull * k), b = tc_splitmix64_at(base, 2ull * k + 1);
+  tc_blob o;
+  o.x = (int32_t)(((a >> 32) * (uint64_t)W) >> 32);
+  o.y = (int32_t)(((a & 0xffffffffull) * (uint64_t)H) >> 32);
+  o.r = 1 + (int32_t)(((b >> 32) * (uint64_t)(max_radius - 1)) >> 32);
+  o.mode = ((b >> 8) & 0xffffffull) < 5033165ull ? 1 : 0; /* 0.3 * 2^24 */
+  o.src = (int32_t)(((b & 0xffull) * (uint64_t)C) >> 8);
+  return o;
+}
 #endif

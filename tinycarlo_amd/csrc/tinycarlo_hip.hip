@@ -946,6 +946,165 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
   raster_body<THICK, FMT>(a, smem, env);
 }
 
+// ---------------------------------------------------------------------------------------------
+// NoiseObservationWrapper (wrapper/observation.py:15-27) as a pass over a finished class-mask observation.
+// Every operation of the reference is per pixel -- obs[c] |= obs[src] & circle, or obs[c] &= ~circle -- so rows are
+// independent: the frame is taken through LDS as bit-planes band by band (same layout as the rasteriser), the blobs
+// are applied to the band in order, and the band is written back.  A filled cv2.circle whose centre lies inside the
+// image is, row by row, the span centre +- hw[radius][|row - cy|] clipped to the image (Circle() of drawing.cpp paints
+// symmetric spans and its bounding-box tests never reject a row when the centre is inside); hw is tabulated on the
+// host by running that midpoint algorithm once per radius.
+struct NArgs {
+  int N, C, H, W, wpr, band_rows, n_bands;
+  unsigned char* obs;
+  const int* blobs;  // [N][C * n_blobs][5] or NULL: drawn here (tc_rng.h)
+  int n_blobs, max_radius;
+  const unsigned char* hw;  // [max_radius][max_radius]: half width of row offset t of the circle of radius r
+  unsigned long long seed;
+  unsigned int step;
+  unsigned int inv_cpr;  // 2^32 / (W / 16) + 1, for fdiv by the 16-pixel chunks per row
+};
+
+// q / d for q < 2^31 with inv = 2^32 / d + 1 (host): one multiply-high and a fix-up instead of a ~30-instruction
+// runtime division (as first written this kernel spent most of its ~12 k instructions per wavefront dividing indices)
+__device__ __forceinline__ int fdiv(int q, int d, unsigned int inv) {
+  int e = (int)__umulhi((unsigned int)q, inv);
+  e -= (e * d > q);
+  e += ((e + 1) * d <= q);
+  return e;
+}
+
+// LDS: bit-planes of one band | blob rows [nb][5] | per blob the span-table row of its radius [nb][max_radius]
+__global__ __launch_bounds__(TC_NT) void tc_noise_kernel(NArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int env = blockIdx.x, tid = threadIdx.x;
+  if (env >= a.N) return;
+  const int C = a.C, H = a.H, W = a.W, wpr = a.wpr;
+  const int nb = C * a.n_blobs;
+  unsigned int* bits = (unsigned int*)smem;
+  int* lb = (int*)(smem + (size_t)C * a.band_rows * wpr * 4);
+  unsigned char* lhw = (unsigned char*)(lb + nb * 5);
+  unsigned char* out = a.obs + (size_t)env * ((size_t)C * H * W);
+
+  // All blobs of this env at once, one per lane: the draws (or the caller's rows) and, behind them, each blob's row of
+  // the span table, so that the blob loop touches nothing but LDS.
+  for (int k = tid; k < nb; k += TC_NT) {
+    tc_blob bl;
+    if (a.blobs) {
+      const int* p = a.blobs + ((size_t)env * nb + k) * 5;
+      bl.x = p[0];
+      bl.y = p[1];
+      bl.r = p[2];
+      bl.mode = p[3];
+      bl.src = p[4];
+    } else {
+      bl = tc_noise_blob(a.seed, (uint32_t)env, a.step, (uint32_t)k, W, H, a.max_radius, C);
+    }
+    // caller-provided lists are not trusted with LDS indices: an invalid row becomes a blob that touches nothing
+    const bool ok = bl.r >= 1 && bl.r < a.max_radius && (unsigned)bl.x < (unsigned)W && (unsigned)bl.y < (unsigned)H &&
+                    (unsigned)bl.src < (unsigned)C;
+    lb[5 * k] = bl.x;
+    lb[5 * k + 1] = bl.y;
+    lb[5 * k + 2] = ok ? bl.r : -1;
+    lb[5 * k + 3] = bl.mode;
+    lb[5 * k + 4] = ok ? bl.src : 0;
+  }
+  __syncthreads();
+  for (int k = 0; k < nb; k++) {  // row k of lhw = row r_k of the table, entries 0 .. r_k
+    const int r = lb[5 * k + 2];
+    for (int t = tid; t <= r; t += TC_NT) lhw[k * a.max_radius + t] = a.hw[r * a.max_radius + t];
+  }
+
+  // this lane's place in a pass over (row, 32-bit word) and over (row, 16-pixel chunk): fixed for the whole kernel
+  const int lw = wpr <= TC_NT ? wpr : TC_NT;           // words of a row handled side by side
+  const int w_lane = tid % lw, r_lane = tid / lw, r_step = TC_NT / lw;
+  const bool w16 = (W & 15) == 0;                      // rows are whole 16-byte chunks: one lane per chunk, coalesced
+  const int cpr = W >> 4;
+  for (int band = 0; band < a.n_bands; band++) {
+    const int y0 = band * a.band_rows;
+    const int rows = (y0 + a.band_rows < H ? y0 + a.band_rows : H) - y0;
+    if (w16) {  // bytes (0 / 255) -> bits, 16 pixels per lane
+      const int per_plane = rows * cpr;
+      for (int c = 0; c < C; c++) {
+        const unsigned char* pl = out + ((size_t)c * H + y0) * W;  // the band's rows of a plane are contiguous
+        for (int q = tid; q < per_plane; q += TC_NT) {
+          const int row = fdiv(q, cpr, a.inv_cpr), ch = q - row * cpr;
+          const uint4 v = *(const uint4*)(pl + (size_t)q * 16);
+          const unsigned int h = ((((v.x & 0x01010101u) * 0x10204080u) >> 28) & 0xfu) |
+                                 (((((v.y & 0x01010101u) * 0x10204080u) >> 28) & 0xfu) << 4) |
+                                 (((((v.z & 0x01010101u) * 0x10204080u) >> 28) & 0xfu) << 8) |
+                                 (((((v.w & 0x01010101u) * 0x10204080u) >> 28) & 0xfu) << 12);
+          ((unsigned short*)bits)[((c * a.band_rows + row) * wpr) * 2 + ch] = (unsigned short)h;
+        }
+      }
+    } else {
+      for (int c = 0; c < C; c++)
+        for (int row = r_lane; row < rows; row += r_step)
+          for (int w = w_lane; w < wpr; w += lw) {
+            const unsigned char* src = out + ((size_t)c * H + y0 + row) * W + w * 32;
+            unsigned int word = 0;
+            for (int j = 0; j < 32 && w * 32 + j < W; j++) word |= (src[j] ? 1u : 0u) << j;
+            bits[(c * a.band_rows + row) * wpr + w] = word;
+          }
+    }
+    __syncthreads();
+    int c = 0, left = a.n_blobs;  // plane of blob k = k / n_blobs, kept by counting
+    for (int k = 0; k < nb; k++) {  // wrapper/observation.py:16-26, blob after blob
+      const int bx = lb[5 * k], by = lb[5 * k + 1], br = lb[5 * k + 2], mode = lb[5 * k + 3], bsrc = lb[5 * k + 4];
+      const int ylo = by - br > y0 ? by - br : y0;
+      const int yhi = br >= 1 ? (by + br < y0 + rows - 1 ? by + br : y0 + rows - 1) : ylo - 1;
+      const unsigned char* hwk = lhw + k * a.max_radius;
+      for (int row = ylo + r_lane; row <= yhi; row += r_step) {
+        const int t = row > by ? row - by : by - row;
+        const int hw = hwk[t];
+        int xl = bx - hw, xr = bx + hw;
+        xl = xl < 0 ? 0 : xl;
+        xr = xr > W - 1 ? W - 1 : xr;
+        for (int w = w_lane; w < wpr; w += lw) {
+          const int b0 = xl > w * 32 ? xl - w * 32 : 0, b1 = xr < w * 32 + 31 ? xr - w * 32 : 31;
+          if (b1 < b0) continue;
+          const unsigned int mask = (b1 - b0 == 31) ? 0xffffffffu : (((1u << (b1 - b0 + 1)) - 1u) << b0);
+          const int ic = (c * a.band_rows + row - y0) * wpr + w;
+          if (mode)
+            bits[ic] |= bits[(bsrc * a.band_rows + row - y0) * wpr + w] & mask;  // observation.py:22-24
+          else
+            bits[ic] &= ~mask;  // observation.py:26
+        }
+      }
+      __syncthreads();  // the next blob may read what this one wrote
+      if (--left == 0) {
+        c++;
+        left = a.n_blobs;
+      }
+    }
+    if (w16) {  // bits -> bytes, one 16-byte store per lane
+      const int per_plane = rows * cpr;
+      for (int cc = 0; cc < C; cc++) {
+        unsigned char* pl = out + ((size_t)cc * H + y0) * W;
+        for (int q = tid; q < per_plane; q += TC_NT) {
+          const int row = fdiv(q, cpr, a.inv_cpr), ch = q - row * cpr;
+          const unsigned int h = ((const unsigned short*)bits)[((cc * a.band_rows + row) * wpr) * 2 + ch];
+          uint4 o;
+          o.x = spread4(h & 15u);
+          o.y = spread4((h >> 4) & 15u);
+          o.z = spread4((h >> 8) & 15u);
+          o.w = spread4((h >> 12) & 15u);
+          *(uint4*)(pl + (size_t)q * 16) = o;
+        }
+      }
+    } else {
+      for (int cc = 0; cc < C; cc++)
+        for (int row = r_lane; row < rows; row += r_step)
+          for (int w = w_lane; w < wpr; w += lw) {
+            unsigned char* dst = out + ((size_t)cc * H + y0 + row) * W + w * 32;
+            const unsigned int word = bits[(cc * a.band_rows + row) * wpr + w];
+            for (int j = 0; j < 32 && w * 32 + j < W; j++) dst[j] = (word >> j) & 1u ? 255 : 0;
+          }
+    }
+    __syncthreads();
+  }
+}
+
 // Both stages in one launch: the same wavefront simulates its env and then rasterises it.  Saves one kernel
 // boundary (launch gap + one ramp-up / drain of the whole grid) per step.
 template <int K, bool THICK, int FMT>
@@ -1010,6 +1169,11 @@ struct tc_env {
   int prof;    // 0 = off, n = record every n-th tc_step
   int prof_n;  // launches recorded so far
   int prof_calls;
+  // NoiseObservationWrapper: blobs per plane (0 = off), radius bound, the per-radius span table, launch counter
+  int noise_blobs, noise_max_radius;
+  unsigned char* noise_hw;
+  unsigned long long noise_seed;
+  unsigned int noise_step;
   hipEvent_t ev[3][TC_PROF_RING];
 };
 
@@ -1419,6 +1583,7 @@ extern "C" int tc_env_destroy(tc_env* e) {
   if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
   if (e && e->k.terms) (void)hipFree((void*)e->k.terms);
   if (e && e->k.spawn_tab) (void)hipFree((void*)e->k.spawn_tab);
+  if (e && e->noise_hw) (void)hipFree(e->noise_hw);
   delete e;
   return TC_OK;
 }
@@ -1448,6 +1613,103 @@ extern "C" int tc_env_set_camera_per_env(tc_env* e, const double* E, const doubl
   e->k.cam_E = E;
   e->k.cam_K = K;
   return TC_OK;
+}
+
+static int noise_lds_bytes(const tc_env* e) {  // bit-planes of a band + blob rows + one span-table row per blob
+  const int nb = e->k.m.C * e->noise_blobs;
+  return e->k.m.C * e->k.cam.band_rows * e->k.cam.wpr * 4 + nb * 5 * 4 + align_up(nb * e->noise_max_radius, 16);
+}
+
+extern "C" int tc_env_set_noise(tc_env* e, int32_t n_blobs, int32_t max_radius, uint64_t seed) {
+  if (!e || n_blobs < 0) return TC_E_INVALID;
+  if (n_blobs == 0) {
+    e->noise_blobs = 0;
+    return TC_OK;
+  }
+  if (e->k.cam.format != TC_FMT_CLASSES) {
+    set_err("tc_env_set_noise: only class-mask observations (wrapper/observation.py:7)");
+    return TC_E_INVALID;
+  }
+  if (max_radius < 2 || max_radius > 256) {
+    set_err("tc_env_set_noise: max_radius must be in [2, 256] (numpy's randint(1, max_radius) needs >= 2)");
+    return TC_E_INVALID;
+  }
+  // Circle(center, radius, fill) of drawing.cpp run once per radius on the host: per-row half widths
+  std::vector<unsigned char> hw((size_t)max_radius * max_radius, 0);
+  for (int radius = 1; radius < max_radius; radius++) {
+    unsigned char* row = hw.data() + (size_t)radius * max_radius;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+      if (row[dy] < dx) row[dy] = (unsigned char)dx;
+      if (row[dx] < dy) row[dx] = (unsigned char)dy;
+      dy++;
+      err += plus;
+      plus += 2;
+      int mask2 = (err <= 0) - 1;
+      err -= minus & mask2;
+      dx += mask2;
+      minus -= mask2 & 2;
+    }
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  if (e->noise_hw) {
+    HIP_TRY(hipFree(e->noise_hw));
+    e->noise_hw = nullptr;
+  }
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, hw.size()));
+  HIP_TRY(hipMemcpy(p, hw.data(), hw.size(), hipMemcpyHostToDevice));
+  e->noise_hw = (unsigned char*)p;
+  e->noise_blobs = n_blobs;
+  e->noise_max_radius = max_radius;
+  e->noise_seed = seed;
+  e->noise_step = 0;
+  const int lds = noise_lds_bytes(e);
+  if (lds > 160 * 1024) {
+    set_err("tc_env_set_noise: blob tables do not fit one workgroup's LDS");
+    e->noise_blobs = 0;
+    return TC_E_LDS;
+  }
+  if (lds > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)tc_noise_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return TC_OK;
+}
+
+static int launch_noise(tc_env* e, const int32_t* blobs, void* stream) {
+  NArgs n;
+  memset(&n, 0, sizeof(n));
+  const DevCam& c = e->k.cam;
+  n.N = e->k.N;
+  n.C = e->k.m.C;
+  n.H = c.H;
+  n.W = c.W;
+  n.wpr = c.wpr;
+  n.band_rows = c.band_rows;
+  n.n_bands = c.n_bands;
+  n.obs = e->k.b.obs;
+  n.blobs = blobs;
+  n.n_blobs = e->noise_blobs;
+  n.max_radius = e->noise_max_radius;
+  n.hw = e->noise_hw;
+  n.seed = e->noise_seed;
+  n.step = e->noise_step++;
+  n.inv_cpr = (c.W >> 4) > 0 ? (unsigned int)((1ull << 32) / (unsigned)(c.W >> 4) + 1ull) : 0u;
+  hipLaunchKernelGGL(tc_noise_kernel, dim3(n.N), dim3(TC_NT), noise_lds_bytes(e), (hipStream_t)stream, n);
+  HIP_TRY(hipGetLastError());
+  return TC_OK;
+}
+
+extern "C" int tc_noise(tc_env* e, const int32_t* blobs, void* stream) {
+  if (!e) return TC_E_INVALID;
+  if (!e->bound || !e->k.b.obs) {
+    set_err("tc_noise: no observation buffer bound");
+    return TC_E_UNBOUND;
+  }
+  if (e->noise_blobs < 1) {
+    set_err("tc_noise: call tc_env_set_noise first");
+    return TC_E_INVALID;
+  }
+  return launch_noise(e, blobs, stream);
 }
 
 extern "C" int tc_env_set_spawn_table(tc_env* e, const int32_t* nodes, int32_t n, uint64_t seed) {
@@ -1617,6 +1879,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       HIP_TRY(hipEventRecord(e->ev[2][slot], main));
       e->prof_n++;
     }
+    if (e->noise_blobs > 0 && mode == MODE_STEP) return launch_noise(e, nullptr, stream);
     return TC_OK;
   }
   for (int p = 0; p < parts; p++) {
@@ -1640,6 +1903,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     HIP_TRY(hipEventRecord(e->ev[2][slot], main));
     e->prof_n++;
   }
+  if (do_raster && e->noise_blobs > 0 && mode == MODE_STEP) return launch_noise(e, nullptr, stream);
   return TC_OK;
 }
 

@@ -109,6 +109,7 @@ class TinyCarloVecEnv(gym.Env):
         # torch-side (non-fused) wrappers ask for the mask of envs an autoreset step re-spawned: those did not go
         # through Wrapper.step in the reference's flow (reset() bypasses the wrappers)
         self.track_fresh = False
+        self.noise = (0, 0, 0)  # (n_blobs, max_radius, seed) of set_noise
         self.last_fresh: Optional[torch.Tensor] = None
 
     def _setup_device(self) -> None:
@@ -234,6 +235,30 @@ class TinyCarloVecEnv(gym.Env):
         """Appends one term (the next wrapper of the stack); returns its slot in `term_counters`."""
         self.set_terms(self.terms + [term])
         return len(self.terms) - 1
+
+    # ------------------------------------------------------------------ NoiseObservationWrapper (wrapper/observation.py)
+    def set_noise(self, n_blobs: int, max_radius: int = 100, seed: int = 0) -> None:
+        """Blob noise on class-mask observations after every step (tc_env_set_noise); n_blobs = 0 switches it off.
+        Blobs are drawn on the device -- the reference's global ``np.random`` stream cannot be reproduced for a batch."""
+        if n_blobs and self._fmt != nat.FMT_CLASSES:
+            raise ValueError("observation noise needs observation_space_format='classes' (wrapper/observation.py:7)")
+        self._push_noise(int(n_blobs), int(max_radius), int(seed) & 0xFFFFFFFFFFFFFFFF)
+        self.noise = (int(n_blobs), int(max_radius), int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+    def _push_noise(self, n_blobs: int, max_radius: int, seed: int) -> None:
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_env_set_noise(self._h, n_blobs, max_radius, seed), "tc_env_set_noise")
+
+    def apply_noise(self, blobs=None) -> torch.Tensor:
+        """The noise pass alone on the current observation.  blobs: int32 [N, n_classes * n_blobs, 5] rows
+        (x, y, radius, mode, src) to use instead of device-drawn ones (mode 1 = copy from plane src, 0 = erase)."""
+        bt = None
+        if blobs is not None:
+            bt = self._to_dev("blobs", blobs, torch.int32, (self.num_envs, self.n_classes * self.noise[0], 5))
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_noise(self._h, bt.data_ptr() if bt is not None else None, self._stream()), "tc_noise")
+        self._keep = (bt,)
+        return self.out["obs"]
 
     def _to_dev(self, key: str, a, dtype: torch.dtype, shape: Tuple[int, ...]) -> torch.Tensor:
         if isinstance(a, torch.Tensor):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Step time of BASELINE config 3 (4096 envs, simple_layout, 64x64 classes, autoreset) with the 7-wrapper stack "A"
-of tests/golden/wrappers.json: none / fused into the step kernel / torch-side.  Prints one JSON line.
+of tests/golden/wrappers.json: none / fused into the step kernel / torch-side, and with NoiseObservationWrapper
+(its own kernel after each step).  Prints one JSON line.
 Usage: python tools/bench_wrappers.py [--envs 4096] [--steps 300]"""
 import argparse
 import copy
@@ -35,10 +36,12 @@ def main():
         spec = next(c["spec"] for c in json.load(f)["cases"] if c["stack"] == "A" and "simple_layout" in c["rollout"])
     N = a.envs
     res = {}
-    for mode in ("none", "fused", "torch"):
+    for mode in ("none", "fused", "noise", "torch"):
         env = TinyCarloVecEnv(copy.deepcopy(cfg), num_envs=N, device="cuda:0", autoreset=True)
         w = env
-        if mode != "none":
+        if mode == "noise":   # NoiseObservationWrapper with the reference's defaults: 10 blobs per plane, radius < 100
+            w = W.NoiseObservationWrapper(env)
+        elif mode != "none":
             for cls, kw in spec:
                 w = getattr(W, cls)(w, **kw, fuse=(mode == "fused"))
         w.reset(seed=0)
