@@ -15,7 +15,8 @@ import numpy as np
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinycarlo_hip.so")
+# TINYCARLO_HIP_LIB: load another build of the same library (tools/phase_clock.py uses the instrumented one)
+LIB_PATH = os.environ.get("TINYCARLO_HIP_LIB") or os.path.join(_HERE, "libtinycarlo_hip.so")
 
 ABI_VERSION = 2
 MAX_TERMS, MAX_LAYERS = 8, 16

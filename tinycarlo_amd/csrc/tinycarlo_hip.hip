@@ -23,6 +23,23 @@
 #include "tc_device.h"
 #include "tc_rng.h"
 
+// Timing build only (make timing -> libtinycarlo_hip_timing.so, used by tools/phase_clock.py): every wavefront stores
+// the shader clock at its phase boundaries.  The shipped library is compiled without TC_TIMING and contains none of it.
+#ifdef TC_TIMING
+__device__ long long* tc_tstamp = nullptr;  // [N][32]
+// (outstanding memory operations are drained first, so a phase is charged with the latencies it started)
+#define TSTAMP(i)                                                                          \
+  do {                                                                                     \
+    long long* _tp = tc_tstamp;                                                            \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                            \
+    if (_tp && threadIdx.x == 0) _tp[(size_t)env * 32 + (i)] = clock64();                  \
+  } while (0)
+#else
+#define TSTAMP(i) \
+  do {            \
+  } while (0)
+#endif
+
 #define TC_PROF_RING 64
 #define TC_MAX_SPLIT 8
 #define MODE_STEP 0
@@ -295,6 +312,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
   const int tid = threadIdx.x;
   if (mode == MODE_RESET && mask && !mask[env]) return false;  // whole workgroup skips: no barrier below is reached
 
+  TSTAMP(0);
   const DevMap& m = a.m;
   const tc_buffers& b = a.b;
   // map windows of 64*K nodes / edges; one window (the usual case) is fetched now and kept in registers
@@ -373,6 +391,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     }
   }
 
+  TSTAMP(1);
   if (mode != MODE_RENDER) {
     // ---- write the state back + scalar info (lane 0)
     const bool have_info = !fresh && s.lp_len >= 2;
@@ -425,6 +444,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
       b.local_path[env * 8 + tid] = v;
     }
 
+    TSTAMP(2);
     // ---- phase B: lane-line distances (car.py:55-64)
     const int C = m.C;
     double dist_l = 0;  // lane l < C: distance to lane-line layer l (0 while the info is empty, car.py:47-51)
@@ -438,6 +458,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
         }
       }
       __syncthreads();
+      TSTAMP(14);
       int my_e = -1;
       for (int l = 0; l < C; l++) {
         const int eo = m.edge_off[l], eend = m.edge_off[l + 1];
@@ -460,6 +481,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
         wave_argmin(bd, best);
         if (tid == l) my_e = best;
       }
+      TSTAMP(15);
       if (tid < C) {
         const int l = tid;
         if (my_e >= 0) {
@@ -477,6 +499,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
         b.laneline_distances[(size_t)env * C + l] = dist_l;
         b.nearest_edge[(size_t)env * C + l] = my_e;
       }
+      TSTAMP(16);
       __syncthreads();  // dn aliases the camera's node buffer
     } else if (tid < C) {
       b.laneline_distances[(size_t)env * C + tid] = 0;
@@ -497,6 +520,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     }
   }
 
+  TSTAMP(3);
   // ---- phase C: camera (camera.py:52-110) + raster (renderer.py:36-51)
   if ((flags & TC_F_NO_OBSERVATION) || b.obs == nullptr) return false;
   if (flags & DBG_SKIP_CAMERA) return false;
@@ -562,13 +586,18 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
       }
     }
     __syncthreads();
+    TSTAMP(4);
     cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, true, -0.0000001, list, cnt + 0);   // camera.py:71-74
+    TSTAMP(17);
     cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, false, -0.0000001, list, cnt + 1);  // camera.py:75-77
+    TSTAMP(18);
     for (int i = tid; i < nn; i += TC_NT)
       if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
     __syncthreads();
     cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, true, -cam.max_range, list, cnt + 2);   // camera.py:81-83
+    TSTAMP(19);
     cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, false, -cam.max_range, list, cnt + 3);  // camera.py:84-86
+    TSTAMP(5);
     // Only nodes in front AND in range can be "visible" (camera.py:92-93): compact them so the two f64
     // divisions of the projection are paid for those nodes only.
     for (int i = tid; i < nn; i += TC_NT)
@@ -584,6 +613,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
       flg[i] |= vis ? (4 | 8) : 8;  // 8: slot Px[i] now holds the int32 pixel coordinates
     }
     __syncthreads();
+    TSTAMP(6);
     for (int w = 0; w < nwe; w++) {  // camera.py:95
       if (reload) cache_edges(mc, m, ge0 + w * K * TC_NT, ge0 + ne, gn0);
 #pragma unroll
@@ -611,6 +641,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     }
     __syncthreads();  // the next group reuses the node buffer and the counters
   }
+  TSTAMP(7);
   if (tid == 0) a.seg_n[env] = *seg_cnt;  // handed to the raster stage through global memory
   return true;
 }
@@ -657,6 +688,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
   unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
   const int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;
   const int nseg = a.seg_n[env];
+  TSTAMP(8);
   unsigned int used_layers = 0;  // layers that have at least one segment in this frame (wave-uniform)
   for (int k = tid; k < nseg; k += TC_NT) used_layers |= 1u << segg[5 * k];
 #pragma unroll
@@ -681,6 +713,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
     const int nwords = C * cam.band_rows * wpr;
     for (int i = tid; i < nwords; i += TC_NT) bits[i] = 0;
     __syncthreads();
+    TSTAMP(9);
     Ras r;
     r.W = W;
     r.H = H;
@@ -706,7 +739,9 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
           if (tid < nb) {
             const int* sg = segg + 5 * (base + tid);
             long long qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3;
+            TSTAMP(20);
             if (!(a.flags & DBG_SKIP_QUAD) && r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
+              TSTAMP(21);
               okq = 1;
               dpx = (int)(qx0 - (long long)sg[1] * TC_XY_ONE);
               dpy = (int)(qy0 - (long long)sg[2] * TC_XY_ONE);
@@ -714,6 +749,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
               if (!(a.flags & DBG_SKIP_EVENTS))
               np = r_fill_events(W, H, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, fpy + 4 * tid, fpv + 4 * tid, wm, lo,
                                  hi);
+              TSTAMP(22);
               if (lo < y0) lo = y0;
               if (hi > y1 - 1) hi = y1 - 1;
               if (np > 0 && hi >= lo) nrow = hi - lo + 1;
@@ -726,6 +762,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
           fd[2 * tid + 1] = dpy;
         }
         __syncthreads();
+        TSTAMP(10);
         for (int t = tid; t < RB * 4; t += TC_NT) {  // outline edges: clip + DDA parameters
           int nchunk = 0;
           if (t < nb * 4 && ((fm[t >> 2] >> 16) & 1)) {
@@ -779,6 +816,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
           if (tid < RB) fc[tid] = finc - f;
         }
         __syncthreads();
+        TSTAMP(11);
         for (int c = tid; c < tot_l && !(a.flags & DBG_SKIP_R2); c += TC_NT) {  // outline pixels, LCH steps per chunk
           int lo = 0, hi = RB * 4;
           while (hi - lo > 1) {
@@ -817,6 +855,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
       }
     }
     __syncthreads();
+    TSTAMP(12);
     if (a.flags & DBG_SKIP_STORE) {
     } else if (FMT == TC_FMT_CLASSES) {
       if ((W & 15) == 0) {
@@ -935,6 +974,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
     }
     __syncthreads();
   }
+  TSTAMP(13);
 }
 
 template <bool THICK, int FMT>
@@ -1620,6 +1660,38 @@ static int noise_lds_bytes(const tc_env* e) {  // bit-planes of a band + blob ro
   return e->k.m.C * e->k.cam.band_rows * e->k.cam.wpr * 4 + nb * 5 * 4 + align_up(nb * e->noise_max_radius, 16);
 }
 
+#ifdef TC_TIMING
+// timing build only: a [n_envs][32] buffer of shader-clock stamps (see TSTAMP); read() copies it to the host
+// The buffer must cover every env of every launch made while it is installed: install it BEFORE the first launch of an
+// env handle and remove it (n_envs = 0) before using a larger one -- a stale smaller buffer is an out-of-bounds write.
+static long long* g_tstamp = nullptr;
+static int g_tstamp_n = 0;
+extern "C" int tc_debug_tstamp_alloc(int n_envs) {
+  HIP_TRY(hipDeviceSynchronize());
+  long long* none = nullptr;
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tc_tstamp), &none, sizeof(none)));
+  if (g_tstamp) HIP_TRY(hipFree(g_tstamp));
+  g_tstamp = nullptr;
+  g_tstamp_n = 0;
+  if (n_envs <= 0) return TC_OK;
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, (size_t)n_envs * 32 * sizeof(long long)));
+  HIP_TRY(hipMemset(p, 0, (size_t)n_envs * 32 * sizeof(long long)));
+  g_tstamp = (long long*)p;
+  g_tstamp_n = n_envs;
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tc_tstamp), &g_tstamp, sizeof(g_tstamp)));
+  return TC_OK;
+}
+// copies the stamps of the last launch to the host and zeroes them (a probe a wavefront skipped then reads 0)
+extern "C" int tc_debug_tstamp_read(long long* out, int n_envs) {
+  if (!g_tstamp || n_envs != g_tstamp_n) return TC_E_INVALID;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, g_tstamp, (size_t)n_envs * 32 * sizeof(long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(g_tstamp, 0, (size_t)n_envs * 32 * sizeof(long long)));
+  return TC_OK;
+}
+#endif
+
 extern "C" int tc_env_set_noise(tc_env* e, int32_t n_blobs, int32_t max_radius, uint64_t seed) {
   if (!e || n_blobs < 0) return TC_E_INVALID;
   if (n_blobs == 0) {
@@ -1828,6 +1900,12 @@ static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_c
 
 static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
                          void* stream, int env0 = 0, int count = -1) {
+#ifdef TC_TIMING
+  if (g_tstamp && e->k.N > g_tstamp_n) {
+    set_err("timing build: the installed stamp buffer is smaller than this env batch");
+    return TC_E_INVALID;
+  }
+#endif
   RArgs r = make_rargs(e, seg_g, seg_n, seg_cap, mask, flags, env0);
   if (count < 0) count = e->k.N;
   const bool thick = r.cam.thickness > 1, cls = r.cam.format == TC_FMT_CLASSES;
@@ -1853,6 +1931,12 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     set_err("TC_F_DEVICE_SPAWN needs a table (tc_env_set_spawn_table)");
     return TC_E_INVALID;
   }
+#ifdef TC_TIMING
+  if (g_tstamp && e->k.N > g_tstamp_n) {
+    set_err("timing build: the installed stamp buffer is smaller than this env batch");
+    return TC_E_INVALID;
+  }
+#endif
   const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;
   const int slot = e->prof_n % TC_PROF_RING;
   const int kv = e->kvar;

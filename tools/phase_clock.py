@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock split of ONE wavefront's pass through the step kernel, from the instrumented build
+(make -C tinycarlo_amd/csrc timing).  Usage: python tools/phase_clock.py [--envs 64 4096] [--steps 40]
+Prints, per batch size, the mean over envs and steps of the clock deltas between the probes (TSTAMP in
+tinycarlo_hip.hip) and each delta's share of the wavefront's lifetime."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["TINYCARLO_HIP_LIB"] = os.path.join(ROOT, "tinycarlo_amd", "libtinycarlo_hip_timing.so")
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+from tinycarlo_amd import _native as nat  # noqa: E402
+from tinycarlo_amd.config import bundled_config  # noqa: E402
+from tinycarlo_amd.vec_env import TinyCarloVecEnv  # noqa: E402
+
+NAMES = ["entry -> tracking done (phase A)", "state / info write-back", "lane-line distances (phase B)",
+         "camera: pose + node transform", "camera: 4 clip passes", "camera: range flags + compaction + projection",
+         "camera: draw list", "hand-off to the raster stage", "raster: layer mask, zero planes",
+         "raster: quad + fill events", "raster: outline clip/DDA, slopes, prefix sums", "raster: pixels (outline, fill, caps)",
+         "raster: expand + store"]
+
+
+# (name, from probe, to probe) inside the big phases
+SUB = [("B: node distances + sync", 2, 14), ("B: 5 x (edge scan + wave argmin)", 14, 15), ("B: per-layer tail (loads, bounds, distance)", 15, 16),
+       ("clip pass 1 (behind -> front)", 4, 17), ("clip pass 2", 17, 18), ("range flags + clip pass 3", 18, 19), ("clip pass 4", 19, 5),
+       ("setup: table offsets, segment fetch", 9, 20), ("setup: ThickLine quad (sqrt, div, rounding)", 20, 21),
+       ("setup: fill events", 21, 22), ("setup: table writes + sync", 22, 10)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, nargs="+", default=[64, 4096])
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--workload", default="cfg3")
+    a = ap.parse_args()
+    mp, res = ("simple_layout", [64, 64]) if a.workload == "cfg3" else ("knuffingen", [128, 128])
+    path = bundled_config(f"config_{mp}.yaml")
+    cfg = yaml.safe_load(open(path))
+    cfg["camera"]["resolution"] = res
+    cfg["sim"]["observation_space_format"] = "classes"
+    cfg["map"]["json_path"] = os.path.join(os.path.dirname(path), cfg["map"]["json_path"])
+    L = nat.lib()
+    L.tc_debug_tstamp_alloc.argtypes = [C.c_int]
+    L.tc_debug_tstamp_read.argtypes = [C.c_void_p, C.c_int]
+    for N in a.envs:
+        nat.check(L.tc_debug_tstamp_alloc(N), "tstamp_alloc")   # before ANY launch of this batch size
+        env = TinyCarloVecEnv(cfg, num_envs=N, device="cuda:0", autoreset=True)
+        env.reset(seed=0)
+        g = torch.Generator(device="cuda:0").manual_seed(0)
+        acc = np.zeros(13)
+        sub = {}
+        life = 0.0
+        n = 0
+        for t in range(a.steps + 10):
+            cc = torch.stack([torch.rand(N, device="cuda:0", generator=g) * 0.7 + 0.3,
+                              torch.rand(N, device="cuda:0", generator=g) * 2 - 1], dim=1)
+            mn = torch.randint(0, 4, (N,), device="cuda:0", generator=g, dtype=torch.int32)
+            env.step_device(cc, mn)
+            if t < 10:
+                continue
+            st = np.zeros((N, 32), dtype=np.int64)
+            nat.check(L.tc_debug_tstamp_read(st.ctypes.data, N), "tstamp_read")
+            ok = (st[:, :23] > 0).all(axis=1)          # envs that ran every phase (not re-spawned without info etc.)
+            d = np.diff(st[ok, :14], axis=1)
+            acc += d.mean(axis=0)
+            life += (st[ok, 13] - st[ok, 0]).mean()
+            for name, i0, i1 in SUB:
+                sub[name] = sub.get(name, 0.0) + (st[ok, i1] - st[ok, i0]).mean()
+            n += 1
+        acc /= n
+        life /= n
+        print(f"--- {a.workload}, {N} envs: wavefront lifetime {life:.0f} clocks (mean over envs that ran every phase)")
+        for name, v in zip(NAMES, acc):
+            print(f"  {name:52s} {v:9.0f}  {100 * v / life:5.1f} %")
+        print("  second level:")
+        for name, _, _ in SUB:
+            print(f"    {name:50s} {sub[name] / n:9.0f}")
+        env.close()
+        nat.check(L.tc_debug_tstamp_alloc(0), "tstamp_free")     # nothing stays installed
+
+
+if __name__ == "__main__":
+    main()
