@@ -19,6 +19,9 @@ _cache = {}
 
 # configs that are test inputs only (tests/golden/): the synthetic maps of make_stress_map.py
 TEST_CFG = {"stress_graph": "config_stress_graph.yaml", "oneway": "config_oneway.yaml"}
+# random maps the reference was run on (gen_golden.py fuzz): fuzz2000 .. fuzz2007
+FUZZ_MAPS = sorted(f[len("config_"):-len(".yaml")] for f in os.listdir(GOLDEN) if f.startswith("config_fuzz") and f.endswith(".yaml"))
+TEST_CFG.update({n: f"config_{n}.yaml" for n in FUZZ_MAPS})
 
 
 def load_cfg(map_name):

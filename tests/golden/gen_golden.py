@@ -87,6 +87,7 @@ EXTRA_MAPS = {
     "stress_graph": os.path.join(OUT, "config_stress_graph.yaml"),
     "oneway": os.path.join(OUT, "config_oneway.yaml"),
 }
+SELF_RELATIVE = {"stress_graph", "oneway"}   # maps of this repo: json_path is relative to the config file itself
 RESOLUTIONS = {"r64": [64, 64], "r128": [128, 128], "r480": [480, 640]}
 
 
@@ -94,7 +95,7 @@ def load(map_name):
     if map_name in EXTRA_MAPS:
         with open(EXTRA_MAPS[map_name]) as f:
             cfg = yaml.safe_load(f)
-        if map_name in ("stress_graph", "oneway"):
+        if map_name in SELF_RELATIVE:
             path = EXTRA_MAPS[map_name]
         else:
             path = os.path.join(REF, "examples", "x.yaml")  # json_path is relative to the reference's examples/
@@ -335,9 +336,10 @@ def single_steps(map_name, n, seed):
         cc = clip_action(v, s)
         try:
             trunc = car.step(cc[0], cc[1], man)
-        except TypeError:
+        except (TypeError, ValueError) as ex:   # car.py:143 (U-turn without an edge) / layer.py:123 (all self-loops)
             n_exc += 1
-            rec_exc.add(v=v, s=s, maneuver=man, **{"pre_" + k: v_ for k, v_ in pre.items()})
+            rec_exc.add(v=v, s=s, maneuver=man, kind=1 if isinstance(ex, TypeError) else 2,
+                        **{"pre_" + k: v_ for k, v_ in pre.items()})
             continue
         post = state_vec(car)
         cte, he, dist, lpc, nlpc, vel = info_vec(m, car)
@@ -643,6 +645,38 @@ def main_exceptions():
           "ok-and-truncated", int((out["truncated"] & (out["outcome"] == 0)).sum()))
 
 
+def main_fuzz():
+    """The reference on random maps (tests/test_gpu_map_fuzz.py:random_map, seeds 2000..2007): 400 single steps each,
+    exceptions recorded with their kind.  Writes the maps and their configs next to this file as test inputs."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    src = open(os.path.join(os.path.dirname(OUT), "test_gpu_map_fuzz.py")).read()
+    ns = {}
+    exec(compile(src[src.index("def random_map"):src.index("# TC_FUZZ_SEEDS")], "random_map", "exec"), {"math": math, "np": np}, ns)
+    random_map = ns["random_map"]
+    base_cfg = yaml.safe_load(open(EXTRA_MAPS["stress_graph"]))
+    for seed in range(2000, 2008):
+        rng = np.random.default_rng(seed)
+        mj = random_map(rng)
+        name = f"fuzz{seed}"
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(mj, f)
+        cfg = {k: dict(v) for k, v in base_cfg.items()}
+        cfg["map"] = {"json_path": f"./{name}.json", "pixel_per_meter": int(rng.choice([200, 300, 450]))}
+        cfg["car"]["max_velocity"] = float(rng.choice([0.15, 0.5]))
+        with open(os.path.join(OUT, f"config_{name}.yaml"), "w") as f:
+            f.write("# Test input generated by gen_golden.py fuzz (random_map of tests/test_gpu_map_fuzz.py)\n")
+            yaml.safe_dump(cfg, f)
+        EXTRA_MAPS[name] = os.path.join(OUT, f"config_{name}.yaml")
+        SELF_RELATIVE.add(name)
+        out = single_steps(name, 400, seed)
+        np.savez_compressed(os.path.join(OUT, f"single_{name}.npz"), **out)
+        ek = out.get("exc_kind", np.zeros(0, dtype=int))
+        lp = mj["lanepath"]
+        deg = np.bincount([e[0] for e in lp["edges"]], minlength=len(lp["nodes"]))
+        print(name, "lanepath", len(lp["nodes"]), "nodes, max out-degree", int(deg.max()), "layers", len(mj["lanelines"]),
+              "| steps 400 trunc", int(out["truncated"].sum()), "TypeError", int((ek == 1).sum()), "ValueError", int((ek == 2).sum()))
+
+
 def main_stress():
     """rollouts on the synthetic stress map: hub with 5 successors / predecessors, dead end, self-loops, duplicate and
     zero-length edges"""
@@ -811,6 +845,8 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         main_extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fuzz":
+        main_fuzz()
     elif len(sys.argv) > 1 and sys.argv[1] == "noise":
         install_gymnasium_stub()
         noise_draws()

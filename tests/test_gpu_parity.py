@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import orc
-from common import cam_keys, golden, load_cfg, map_of, rollout_files, setup
+from common import FUZZ_MAPS, cam_keys, golden, load_cfg, map_of, rollout_files, setup
 
 pytestmark = pytest.mark.gpu
 
@@ -132,7 +132,7 @@ def test_golden_teacher_forced(fname):
     env.close()
 
 
-@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen", "stress_graph"])
+@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen", "stress_graph"] + FUZZ_MAPS)
 def test_golden_single_steps(mp):
     d = golden(f"single_{mp}.npz")
     T = len(d["v"])

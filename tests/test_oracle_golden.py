@@ -18,7 +18,7 @@ import pytest
 
 import orc
 from tinycarlo_amd.camera import Camera
-from common import GOLDEN, cam_keys, golden, load_cfg, map_of, rollout_files, setup
+from common import FUZZ_MAPS, GOLDEN, cam_keys, golden, load_cfg, map_of, rollout_files, setup
 
 FTOL = 1e-12
 
@@ -158,9 +158,10 @@ def test_rollout_free_running(fname):
 
 
 @pytest.mark.parametrize("mode,tol", [(orc.MATH_LIBM, FTOL), (orc.MATH_PORTABLE, 1e-9)])
-@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen", "stress_graph"])
+@pytest.mark.parametrize("mp", ["simple_layout", "knuffingen", "stress_graph"] + FUZZ_MAPS)
 def test_single_steps(mp, mode, tol):
-    """4000 independent (state, action) pairs per map: U-turns, reverse, all maneuvers, truncations."""
+    """Independent (state, action) pairs per map (4000 on the bundled maps, 3000 on the stress map, 400 on each of the
+    random maps of gen_golden.py fuzz): U-turns, reverse, all maneuvers, truncations."""
     d = golden(f"single_{mp}.npz")
     _, m, car, cam = setup(mp, "r64")
     orc.set_math_mode(mode)
@@ -171,7 +172,7 @@ def test_single_steps(mp, mode, tol):
         o.state[:] = _states_from(d, "pre_")
         o.step(np.stack([d["v"], d["s"]], axis=1), d["maneuver"], flags=orc.F_WRAPPED, with_obs=False)
         _check_batch(o, d, C, tol)
-        assert int(((d["maneuver"] == 2) & (d["pre_last_maneuver"] != 2)).sum()) > 100
+        assert int(((d["maneuver"] == 2) & (d["pre_last_maneuver"] != 2)).sum()) > T // 40   # U-turn searches took part
     finally:
         orc.set_math_mode(orc.MATH_LIBM)
 
