@@ -26,7 +26,9 @@ NAMES = ["entry -> tracking done (phase A)", "state / info write-back", "lane-li
          "raster: expand + store"]
 
 
-# (name, from probe, to probe) inside the big phases
+# (name, from probe, to probe) inside the big phases.  Probes 20-22 sit inside the rasteriser's batch loop (32 segments
+# per batch) and keep the LAST batch's stamps: for frames with more than 32 segments the "setup:" intervals mix batches
+# (the first one then contains a whole batch and the last one goes negative); the first-level table is not affected.
 SUB = [("B: node distances + sync", 2, 14), ("B: 5 x (edge scan + wave argmin)", 14, 15), ("B: per-layer tail (loads, bounds, distance)", 15, 16),
        ("clip pass 1 (behind -> front)", 4, 17), ("clip pass 2", 17, 18), ("range flags + clip pass 3", 18, 19), ("clip pass 4", 19, 5),
        ("setup: table offsets, segment fetch", 9, 20), ("setup: ThickLine quad (sqrt, div, rounding)", 20, 21),
