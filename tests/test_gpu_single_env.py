@@ -1,0 +1,85 @@
+"""The drop-in boundary of SURVEY 8b on the real engine: `gym.make("tinycarlo-v2", config=...)` / `TinyCarloEnv` with the
+HIP library underneath (tests/test_host_logic.py runs the same checks on the CPU with the oracle injected as engine;
+here nothing is injected).  The test bodies are the ones of test_host_logic.py, called as plain functions."""
+import numpy as np
+import pytest
+
+import test_host_logic as H
+from common import rollout_files
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(autouse=True)
+def _real_engine():
+    from tinycarlo_amd.env import TinyCarloEnv
+    from tinycarlo_amd.vec_env import TinyCarloVecEnv
+    assert TinyCarloEnv._vec_cls is TinyCarloVecEnv   # nothing injected
+    yield
+
+
+def test_make_and_random_control_loop_on_gpu():
+    H.test_make_and_random_control_loop()
+
+
+@pytest.mark.parametrize("fname", [f for f in rollout_files() if "r480" not in f and ("random_0" in f or "stanley_1" in f or "wild_2" in f)])
+def test_env_reproduces_reference_rollout_on_gpu(fname):
+    """reset(seed) + step() through the public single-env API on the GPU reproduce the reference's rollouts: spawn
+    nodes out of the seeded np_random, termination / truncation times, info within 1e-9"""
+    H.test_env_reproduces_reference_rollout(fname)
+
+
+def test_render_no_observation_and_camera_update_on_gpu():
+    H.test_no_observation_and_render()
+    H.test_camera_update_params_changes_frame()
+    H.test_human_render_mode_rejected_and_config_required()
+
+
+def test_python_wrappers_on_the_single_env_on_gpu():
+    """the reference-style scalar wrappers (python floats from the info dict) stacked on the HIP-backed single env equal
+    the fused batched terms of a 1-env TinyCarloVecEnv driven with the same actions"""
+    from common import build_stack, wrapper_cases
+    from tinycarlo_amd.env import TinyCarloEnv
+    from tinycarlo_amd.vec_env import TinyCarloVecEnv
+    spec = next(c["spec"] for c in wrapper_cases()["cases"] if c["stack"] == "A" and "simple_layout" in c["rollout"])
+    cfg = H.cfg_for("simple_layout", "r64")
+    single = build_stack(TinyCarloEnv(config=cfg), spec)
+    vec_e = TinyCarloVecEnv(cfg, num_envs=1, device="cuda:0")
+    vec = build_stack(vec_e, spec)
+    assert vec.fused and not getattr(single, "fused", False)
+    single.reset(seed=9)
+    vec.reset(seed=9)
+    fired = 0
+    for t in range(80):
+        v, s_, man = 0.7, 0.5 * np.sin(t / 6), (t // 16) % 4
+        _, r1, te1, tr1, _ = single.step({"car_control": [v, s_], "maneuver": man})
+        _, r2, te2, tr2, _ = vec.step({"car_control": np.array([[v, s_]]), "maneuver": np.array([man], dtype=np.int32)})
+        assert r1 == float(r2[0]) and te1 == bool(te2[0]) and tr1 == bool(tr2[0]), t
+        fired += te1
+    assert fired > 0
+    single.close()
+    vec_e.close()
+
+
+def test_noise_wrapper_single_env_path_on_gpu():
+    """NoiseObservationWrapper on the single env: numpy draws in the reference's order applied to the GPU-rendered frame"""
+    from tinycarlo_amd.env import TinyCarloEnv
+    from tinycarlo_amd.wrapper import NoiseObservationWrapper
+    from tinycarlo_amd.wrapper.observation import apply_blobs, draw_blobs
+    cfg = H.cfg_for("simple_layout", "r64", "classes")
+    clean = TinyCarloEnv(config=cfg)
+    noisy = NoiseObservationWrapper(TinyCarloEnv(config=cfg), blob_max_radius=30, n_blobs=4)
+    assert not noisy.engine_side and noisy.unwrapped.wrapped
+    clean.reset(seed=3)
+    noisy.reset(seed=3)
+    act = {"car_control": [0.6, 0.1], "maneuver": 0}
+    for t in range(3):
+        o0, *_ = clean.step(act)
+        np.random.seed(100 + t)
+        o1, *_ = noisy.step(act)
+        np.random.seed(100 + t)
+        want = apply_blobs(o0.copy(), draw_blobs(5, 64, 64, 4, 30), 4)
+        assert np.array_equal(o1, want) and not np.array_equal(o1, o0)
+    clean.close()
+    noisy.close()
