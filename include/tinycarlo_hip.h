@@ -194,7 +194,9 @@ int tc_env_set_spawn_table(tc_env* env, const int32_t* nodes, int32_t n, uint64_
  * circle or ORs in the circle-masked content of a random plane, applied in order.  With n_blobs > 0 every tc_step
  * that renders an observation is followed by the noise kernel on the same stream, blobs drawn on the device
  * (tinycarlo_amd/csrc/tc_rng.h; the reference draws from the global numpy generator, which cannot be reproduced
- * for a batch).  n_blobs = 0 switches it off.  Needs TC_FMT_CLASSES and max_radius in [2, 256]. */
+ * for a batch).  The position in the blob stream is a counter in device memory advanced on the stream after every
+ * device-drawn pass, so a tc_step captured into a HIP graph draws new blobs on every replay.  n_blobs = 0 switches the
+ * noise off.  Needs TC_FMT_CLASSES and max_radius in [2, 256]. */
 int tc_env_set_noise(tc_env* env, int32_t n_blobs, int32_t max_radius, uint64_t seed);
 /* The noise pass alone, on the currently bound observation.  blobs: device int32 [N][n_layers * n_blobs][5] rows
  * (x, y, radius, mode, src) -- blob k belongs to plane k / n_blobs, mode 1 = copy from plane src, 0 = erase -- or

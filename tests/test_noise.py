@@ -201,3 +201,40 @@ def test_gpu_noise_error_paths():
     assert L.tc_env_set_noise(env._h, 0, 0, 0) == 0 and L.tc_noise(env._h, None, None) == -1
     torch.cuda.synchronize()
     env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_noise_in_a_captured_graph_advances_its_stream():
+    """A step with noise captured into a HIP graph: every replay must draw the NEXT blobs (the pass counter lives in
+    device memory and is advanced on the stream), i.e. replays equal eager steps bit for bit -- and differ from each
+    other.  With the counter as a kernel argument a replay would repeat the captured draw."""
+    from test_gpu_parity import make_env
+    N = 64
+    env_g = make_env("simple_layout", "r64", "classes", N)
+    env_e = make_env("simple_layout", "r64", "classes", N)
+    for e in (env_g, env_e):
+        e.set_noise(6, 40, seed=5)
+        e.reset(seed=2)
+    cc = torch.zeros((N, 2), dtype=torch.float32, device="cuda:0")
+    cc[:, 0] = 0.5
+    mn = torch.zeros(N, dtype=torch.int32, device="cuda:0")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        env_g.step_device(cc, mn)
+    torch.cuda.current_stream().wait_stream(s)
+    env_e.step_device(cc, mn)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        env_g.step_device(cc, mn)
+    frames = []
+    for t in range(4):
+        g.replay()
+        env_e.step_device(cc, mn)
+        torch.cuda.synchronize()
+        assert torch.equal(env_g.out["obs"], env_e.out["obs"]), t
+        for k in env_e.state:
+            assert torch.equal(env_g.state[k], env_e.state[k]), (t, k)
+        frames.append(env_g.out["obs"].clone())
+    assert not torch.equal(frames[0], frames[1]) and not torch.equal(frames[1], frames[2])
+    env_g.close()
+    env_e.close()

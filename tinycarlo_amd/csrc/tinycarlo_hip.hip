@@ -1001,9 +1001,12 @@ struct NArgs {
   int n_blobs, max_radius;
   const unsigned char* hw;  // [max_radius][max_radius]: half width of row offset t of the circle of radius r
   unsigned long long seed;
-  unsigned int step;
+  const unsigned int* step;  // device counter of noise passes so far (advanced by tc_noise_tick on the same stream:
+                             // a kernel argument would be frozen into a captured HIP graph and replay the same blobs)
   unsigned int inv_cpr;  // 2^32 / (W / 16) + 1, for fdiv by the 16-pixel chunks per row
 };
+
+__global__ void tc_noise_tick(unsigned int* step) { *step += 1; }
 
 // q / d for q < 2^31 with inv = 2^32 / d + 1 (host): one multiply-high and a fix-up instead of a ~30-instruction
 // runtime division (as first written this kernel spent most of its ~12 k instructions per wavefront dividing indices)
@@ -1038,7 +1041,7 @@ __global__ __launch_bounds__(TC_NT) void tc_noise_kernel(NArgs a) {
       bl.mode = p[3];
       bl.src = p[4];
     } else {
-      bl = tc_noise_blob(a.seed, (uint32_t)env, a.step, (uint32_t)k, W, H, a.max_radius, C);
+      bl = tc_noise_blob(a.seed, (uint32_t)env, *a.step, (uint32_t)k, W, H, a.max_radius, C);
     }
     // caller-provided lists are not trusted with LDS indices: an invalid row becomes a blob that touches nothing
     const bool ok = bl.r >= 1 && bl.r < a.max_radius && (unsigned)bl.x < (unsigned)W && (unsigned)bl.y < (unsigned)H &&
@@ -1213,7 +1216,7 @@ struct tc_env {
   int noise_blobs, noise_max_radius;
   unsigned char* noise_hw;
   unsigned long long noise_seed;
-  unsigned int noise_step;
+  unsigned int* noise_step;  // device counter
   hipEvent_t ev[3][TC_PROF_RING];
 };
 
@@ -1624,6 +1627,7 @@ extern "C" int tc_env_destroy(tc_env* e) {
   if (e && e->k.terms) (void)hipFree((void*)e->k.terms);
   if (e && e->k.spawn_tab) (void)hipFree((void*)e->k.spawn_tab);
   if (e && e->noise_hw) (void)hipFree(e->noise_hw);
+  if (e && e->noise_step) (void)hipFree(e->noise_step);
   delete e;
   return TC_OK;
 }
@@ -1735,7 +1739,12 @@ extern "C" int tc_env_set_noise(tc_env* e, int32_t n_blobs, int32_t max_radius, 
   e->noise_blobs = n_blobs;
   e->noise_max_radius = max_radius;
   e->noise_seed = seed;
-  e->noise_step = 0;
+  if (!e->noise_step) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, sizeof(unsigned int)));
+    e->noise_step = (unsigned int*)q;
+  }
+  HIP_TRY(hipMemset(e->noise_step, 0, sizeof(unsigned int)));
   const int lds = noise_lds_bytes(e);
   if (lds > 160 * 1024) {
     set_err("tc_env_set_noise: blob tables do not fit one workgroup's LDS");
@@ -1764,10 +1773,14 @@ static int launch_noise(tc_env* e, const int32_t* blobs, void* stream) {
   n.max_radius = e->noise_max_radius;
   n.hw = e->noise_hw;
   n.seed = e->noise_seed;
-  n.step = e->noise_step++;
+  n.step = e->noise_step;
   n.inv_cpr = (c.W >> 4) > 0 ? (unsigned int)((1ull << 32) / (unsigned)(c.W >> 4) + 1ull) : 0u;
   hipLaunchKernelGGL(tc_noise_kernel, dim3(n.N), dim3(TC_NT), noise_lds_bytes(e), (hipStream_t)stream, n);
   HIP_TRY(hipGetLastError());
+  if (!blobs) {  // device-drawn blobs consumed one position of the stream
+    hipLaunchKernelGGL(tc_noise_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, e->noise_step);
+    HIP_TRY(hipGetLastError());
+  }
   return TC_OK;
 }
 
