@@ -460,12 +460,20 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
       __syncthreads();
       TSTAMP(14);
       int my_e = -1;
+      int cur_w = single ? 0 : -1;  // the edge window mc.ed holds.  A layer's edges are contiguous, so it overlaps one or
+                                    // two windows; reloading every window for every layer was 10 global loads per step
+                                    // on knuffingen (2 windows x 5 layers) where 2 are needed
       for (int l = 0; l < C; l++) {
         const int eo = m.edge_off[l], eend = m.edge_off[l + 1];
         int best = -1;
         double bd = 0;
         for (int w = 0; w < nwin_e; w++) {
-          if (!single) cache_edges(mc, m, w * K * TC_NT, m.total_edges, 0);
+          const int w0 = w * K * TC_NT;
+          if (w0 >= eend || w0 + K * TC_NT <= eo) continue;  // no edge of this layer in the window
+          if (!single && w != cur_w) {
+            cache_edges(mc, m, w0, m.total_edges, 0);
+            cur_w = w;
+          }
 #pragma unroll
           for (int k = 0; k < K; k++) {  // layer.py:43 over this lane's edges of layer l (ascending index)
             const int e = (w * K + k) * TC_NT + tid;
