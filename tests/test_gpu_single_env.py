@@ -83,3 +83,24 @@ def test_noise_wrapper_single_env_path_on_gpu():
         assert np.array_equal(o1, want) and not np.array_equal(o1, o0)
     clean.close()
     noisy.close()
+
+
+def test_examples_run_on_gpu():
+    """examples/: the random-control loop of the single env and the batched on-device Stanley controller -- which must
+    actually track the lane path (the reference's controller settles within a couple of centimetres)"""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "random_control.py"), "--steps", "60"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "60 steps" in r.stdout, r.stderr[-500:]
+    spec = importlib.util.spec_from_file_location("stanley_batched", os.path.join(root, "examples", "stanley_batched.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(num_envs=512, steps=300)
+    assert out["obs_shape"] == (512, 128, 160, 3)
+    assert out["mean_abs_cte_m"] < 0.02, out                 # the cars follow the path
+    assert out["mean_reward_per_step"] > 0.3, out            # |cte| <= 1 cm on a good share of the steps (sparse reward 1)
+    assert out["episodes_ended"] < 512 * 300 * 0.02, out     # and rarely leave it
