@@ -1,0 +1,47 @@
+"""bench.py's output contract (one JSON line; metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+higher_is_better / scaling / vs_baseline / dtype / data / config.workload + roofline{} + cpu_baseline{}), checked on a
+small run so that a regression in bench.py shows up in the GPU suite and not only when the driver runs it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines          # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_default_workload_line():
+    d = _run("--steps", "40", "--warmup", "8", "--cpu-budget", "40000")
+    assert d["metric"] == "env-steps/sec (whole node)" and d["unit"] == "env-steps/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 8
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["config"]["workload"].startswith("cfg3: 4096 envs/GPU") and d["config"]["envs_per_gpu"] == 4096
+    assert abs(d["value"] - 4096 * 40 / (d["ms_per_step"] * 40 / 1e3)) < 1e-6 * d["value"]
+    assert d["value"] > 5e6                                  # the north star's target is 1e6 on this configuration
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "tc_step_kernel"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert r["algorithmic_bytes_per_launch"] == 4096 * (240 + 5 * 64 * 64)
+    assert r["traffic"] is None or r["traffic"] > 0.9 * r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and "oracle" in c["sample"]
+
+
+def test_other_workloads_and_flags():
+    d = _run("--workload", "cfg2", "--steps", "20", "--warmup", "4", "--no-cpu-baseline")
+    assert "cpu_baseline" not in d and d["roofline"]["kernel"] == "tc_env_kernel"
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 4096 * 240
+    d = _run("--workload", "cfg4", "--envs", "256", "--steps", "10", "--warmup", "2", "--no-cpu-baseline")
+    assert d["config"]["envs_per_gpu"] == 256 and d["roofline"]["traffic"] is None     # PMC summary is for the full size only
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 256 * (240 + 5 * 128 * 128)
