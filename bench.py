@@ -5,17 +5,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one batched step() of `--envs` envs per GPU (default 4096): ONE launch of the fused HIP
-kernel (kinematics -> lanepath tracking -> lane-line distances -> camera clip/project -> raster
--> uint8 observation store), inputs (actions) already resident in HBM, observations left in HBM.
+A "step" is one batched step() of `--envs` envs per GPU (default 4096): kinematics -> lanepath tracking -> lane-line
+distances -> camera clip/project -> raster -> uint8 observation store, inputs (actions) already resident in HBM,
+observations left in HBM.  The K timed steps are issued `--steps-per-launch` at a time through tc_step_multi (one
+wavefront stays with its env for all steps of a launch; default 32, `config.steps_per_launch`); every step's
+observation is stored to its own row of a [steps_per_launch, N, ...] rollout buffer, so the bytes written per step
+are the same as with one launch per step (`--steps-per-launch 0` times that form, tc_step).
 Workloads (BASELINE.json configs):
     cfg3 (default)  4096 envs, simple_layout, 64x64 'classes', with camera raster      [the metric's config]
     cfg2            same, no_observation=True (kinematics + tracking + distances only)
     cfg4            4096 envs/GPU, knuffingen, 128x128 'classes'
     cfg5            8192 envs, knuffingen, 480x640 'rgb'
-Envs are sharded over ranks with no data-path collective (they are independent).  `--gather flags|obs` adds the
-optional exchange step on every step (rewards/terminated/truncated, or also observations, to rank 0 over RCCL);
-by default one such gather runs after the timed region only, as a functional check of the RCCL path.
+Envs are sharded over ranks with no data-path collective (they are independent): `value` is the un-gathered rate.  With
+--gpus > 1 the optional exchange step (rewards / flags, and observations, to rank 0 over RCCL) is measured after the
+main region in the same process and reported beside it as `gathered` (separate numbers).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -32,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 B_STATE = 240          # algorithmic state/action/info bytes per env-step
+PROFILE_ROUND = "r02"  # profiles/<round>/<workload>_pmc.json holds the committed PMC summary of this command
 
 WORKLOADS = {
     "cfg2": dict(map="simple_layout", res=[64, 64], fmt="classes", envs=4096, no_obs=True),
@@ -66,17 +70,22 @@ def gen_actions(n_envs, n_steps, seed, device):
     return cc, man
 
 
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
-    (profiles/r01/<workload>_pmc.json: separate --pmc FETCH_SIZE and WRITE_SIZE passes; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950), or None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", f"{workload}_pmc.json")
+def pmc_traffic(workload, kernel, steps_per_launch):
+    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC summary of this command
+    (profiles/<round>/<workload>_pmc.json: separate --pmc FETCH_SIZE and WRITE_SIZE passes; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950), or None when no summary of the same launch shape is committed.
+    It is a profile of an earlier run of this command, not a measurement of this run: `traffic_source` says so."""
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"{workload}_pmc.json")
     try:
         with open(path) as f:
             j = json.load(f)
-        return sum((2 * j[k]["FETCH_SIZE"] + j[k]["WRITE_SIZE"]) * 1024.0 for k in kernel.split("+"))
+        if int(j.get("_steps_per_launch", -1)) != int(steps_per_launch):
+            return None, None
+        b = sum((2 * j[k]["FETCH_SIZE"] + j[k]["WRITE_SIZE"]) * 1024.0 for k in kernel.split("+"))
+        return b, f"profiles/{PROFILE_ROUND}/{workload}_pmc.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                  f"2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction; build {j.get('_build', '?')})"
     except Exception:
-        return None
+        return None, None
 
 
 def host_cores():
@@ -96,23 +105,22 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("TC_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(w, cfg, budget_env_steps):
-    """The CPU oracle (oracle/tc_oracle.c, libm mode, OpenMP over envs) timed on this box's host cores on a
-    bounded sample of the same workload: same map / resolution / format / action distribution."""
+def _cpu_run(w, cfg, threads, budget_env_steps):
+    """The CPU oracle (oracle/tc_oracle.c, libm mode, OpenMP over envs) timed on a bounded sample of the same
+    workload: same map / resolution / format / action distribution."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     from tinycarlo_amd.camera import Camera
     from tinycarlo_amd.config import CarParams
     from tinycarlo_amd.map import Map
     from tinycarlo_amd import gym
-    cores = host_cores()
     m = Map(cfg["map"])
     car = CarParams.from_config(1 / cfg["sim"].get("fps", 30), cfg["car"])
     cam = Camera(cfg["camera"])
-    n = min(w["envs"], 1024)
+    n = min(w["envs"], 1024 if threads > 1 else 256)
     steps = max(4, budget_env_steps // n)
     orc.set_math_mode(orc.MATH_LIBM)
-    o = orc.Oracle(m, car, cam, orc.FMT_CLASSES if w["fmt"] == "classes" else orc.FMT_RGB, n, threads=cores)
+    o = orc.Oracle(m, car, cam, orc.FMT_CLASSES if w["fmt"] == "classes" else orc.FMT_RGB, n, threads=threads)
     rngs = [gym.np_random(i)[0] for i in range(n)]
     o.reset([m.sample_spawn_node(r) for r in rngs], flags=orc.F_NO_OBSERVATION)
     o.spawn_queue = np.array([[m.sample_spawn_node(r) for _ in range(16)] for r in rngs], dtype=np.int32)
@@ -125,22 +133,35 @@ def cpu_baseline(w, cfg, budget_env_steps):
     for t in range(steps):
         o.step(cc[t], man, flags=flags, with_obs=not w["no_obs"])
     dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} steps of the same workload, oracle/tc_oracle.c (scalar f64, libm) with OpenMP over envs, {dt:.1f} s wall"}
+    return n * steps / dt, f"{n} envs x {steps} steps of the same workload, {dt:.1f} s wall"
+
+
+def cpu_baseline(w, cfg, budget_env_steps):
+    """All host cores and ONE thread, each on its own bounded sample; `value` / `cores` is the all-cores run."""
+    cores = host_cores()
+    v_all, s_all = _cpu_run(w, cfg, cores, budget_env_steps)
+    v_one, s_one = _cpu_run(w, cfg, 1, max(budget_env_steps // 8, 20000))
+    return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{s_all}; oracle/tc_oracle.c (scalar f64, libm) with OpenMP over envs",
+            "one_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1, "sample": s_one}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the workload's)")
-    ap.add_argument("--gather", default="none", choices=["none", "flags", "obs"],
-                    help="what is gathered to rank 0 over RCCL on EVERY step when --gpus > 1 (default none: envs are "
-                         "independent, the data path has no collective; one gather is still done after the timed region)")
+    ap.add_argument("--steps-per-launch", type=int, default=None,
+                    help="steps issued per kernel launch through tc_step_multi (default 32; cfg5: 2 -- its rollout rows are "
+                         "7.5 GB each); 0 = one tc_step launch per step")
+    ap.add_argument("--preroll-ms", type=float, default=300.0,
+                    help="untimed steps issued for about this long before the warm-up so that a short run is measured at "
+                         "steady clocks (reported as config.preroll_steps)")
+    ap.add_argument("--no-gathered", action="store_true", help="--gpus > 1: skip the gathered measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=int, default=2000000, help="env-steps of the CPU baseline sample")
+    ap.add_argument("--cpu-budget", type=int, default=2000000, help="env-steps of the all-cores CPU baseline sample")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,80 +186,139 @@ def main():
             dist.init_process_group(backend)
 
     from tinycarlo_amd.vec_env import TinyCarloVecEnv
-    from tinycarlo_amd.distributed import RankGather
+    from tinycarlo_amd.distributed import RankGather, shard_range, shard_seed
 
     w = dict(WORKLOADS[args.workload])
     if args.envs:
         w["envs"] = args.envs
     cfg = make_config(w)
     n = w["envs"]
-    env = TinyCarloVecEnv(cfg, num_envs=n, device=device, autoreset=True, spawn_queue_len=32)
+    lo, hi = shard_range(n * world, rank, world)  # contiguous env shard of this rank (all shards have n envs here)
+    assert hi - lo == n
+    M = args.steps_per_launch
+    if M is None:
+        M = 2 if args.workload == "cfg5" else 32
+    env = TinyCarloVecEnv(cfg, num_envs=n, device=device, autoreset=True, spawn_queue_len=64)
     env.no_observation = w["no_obs"]
-    env.reset(seed=rank * n)  # env i of rank r is the reference env seeded r*n + i
+    env.reset(seed=shard_seed(0, rank, n))  # env i of rank r is the reference env seeded r*n + i
     K, W = args.steps, args.warmup
-    period = min(K + W, 1024)  # distinct action batches kept in HBM (reused cyclically beyond that)
+    period = min(max(K + W, 64), 1024)  # distinct action batches kept in HBM (reused cyclically beyond that)
     cc, man = gen_actions(n, period, seed=rank, device=device)
-    gather = RankGather(env, what=args.gather) if world > 1 and args.gather != "none" else None
+    roll = None
+    if M >= 1 and not w["no_obs"]:
+        roll = env.alloc_rollout(M, keys=("obs", "reward", "terminated", "truncated"))
+    elif M >= 1:
+        roll = env.alloc_rollout(M, keys=("reward", "terminated", "truncated"))
 
-    def run(k0, k):
-        for t in range(k0, k0 + k):
+    def issue(t0, cnt, sink=None, m=None):
+        """steps t0 .. t0+cnt-1 of the action stream, m per launch (default: M); returns the number of launches"""
+        m = M if m is None else m
+        nl = 0
+        if m == 0:
+            for t in range(t0, t0 + cnt):
+                i = t % period
+                env.step_device(cc[i], man[i])
+            return cnt
+        t = t0
+        while t < t0 + cnt:
             i = t % period
-            env.step_device(cc[i], man[i])
-            if gather is not None:
-                gather.step()
+            kk = min(m, t0 + cnt - t, period - i)
+            if sink is not None:
+                sink.launch(cc[i:i + kk], man[i:i + kk])
+            else:
+                r = roll if kk == M else {k_: v[:kk] for k_, v in roll.items()}
+                env.step_multi(cc[i:i + kk], man[i:i + kk], rollout=r)
+            t += kk
+            nl += 1
+        return nl
 
-    run(0, W)
-    env.profile(8)  # HIP events around both kernels of every 8th timed step (every step would serialise the queue)
-    if gather is not None:
-        gather.wait()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(W, K)
-    ev1.record()
-    if gather is not None:
-        gather.wait()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(t0, cnt, sink=None, m=None):
+        """cnt steps bracketed by barrier + synchronize on both sides; MAX over ranks of the wall time"""
+        if sink is not None:
+            sink.wait()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_0 = time.perf_counter()
+        ev0.record()
+        nl = issue(t0, cnt, sink, m)
+        ev1.record()
+        if sink is not None:
+            sink.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t_0
+        ev_ms = ev0.elapsed_time(ev1)
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, ev_ms, nl
 
-    gathered_ok = None
-    # functional check of the optional exchange step over RCCL, outside the timed region.  It must never cost the
-    # measurement: an exception is reported in the JSON line instead (TC_BENCH_GATHER_CHECK=0 skips the check).
-    if dist is not None and backend == "nccl" and os.environ.get("TC_BENCH_GATHER_CHECK", "1") != "0":
-        try:
-            g = gather if gather is not None else RankGather(env, what="flags")
-            g.step()
-            last = g.latest()
-            if rank == 0:
-                gathered_ok = bool(torch.equal(last["reward"][0], env.out["reward"]) and last["reward"].shape[0] == world)
-        except Exception as ex:  # noqa: BLE001 -- reported, not fatal
-            gathered_ok = f"error: {type(ex).__name__}: {ex}"[:200]
+    # untimed pre-roll: the driver's short command (20 steps) would otherwise be measured while the clocks ramp up
+    preroll = 0
+    if args.preroll_ms > 0:
+        chunk = max(M, 32)
+        t_end = time.perf_counter() + args.preroll_ms / 1e3
+        while time.perf_counter() < t_end:
+            issue(preroll % period, chunk)
+            preroll += chunk
+            torch.cuda.synchronize()
+    issue(0, W)
+    # HIP events on the launch stream around the kernel(s) of sampled launches (every launch of a short run; an
+    # event triple on every launch of a long one serialises the queue)
+    n_launch = K if M == 0 else -(-K // M)
+    env.profile(1 if n_launch <= 64 else max(1, n_launch // 48))
+    dt, ev_ms, n_l = timed(W, K)
+    prof = env.profile_read()
+    env.profile(0)
+
+    # --- the optional exchange step, measured after the main region (never inside `value`)
+    gathered = None
+    if dist is not None and not args.no_gathered:
+        gathered = {}
+        Kg = min(K, 256)
+        Mg = max(1, min(M if M >= 1 else 1, 8))  # rank 0 holds world x 2 slots of a launch's rows: keep the slots small
+        for what in ("flags", "obs"):
+            if what == "obs" and w["no_obs"]:
+                continue
+            try:
+                g = RankGather(env, what=what, steps_per_launch=Mg)
+                issue(0, 2 * Mg, g, Mg)  # warm the collective up (communicator set-up is not part of the rate)
+                dtg, _, _ = timed(0, Kg, g, Mg)
+                last = g.latest()
+                ok = None
+                if rank == 0:
+                    ok = bool(last["reward"].shape[0] == world)
+                gathered[what] = {"value": world * n * Kg / dtg, "unit": "env-steps/s", "steps": Kg, "steps_per_launch": Mg,
+                                  "ranks_seen_on_rank0": int(last["reward"].shape[0]) if rank == 0 else None, "ok": ok,
+                                  "bytes_per_rank_per_step": n * (10 + (env.obs_bytes_per_env if what == "obs" else 0))}
+                del g
+            except Exception as ex:  # noqa: BLE001 -- reported in the line, never fatal for the measurement above
+                gathered[what] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        gathered["backend"] = "RCCL (torch.distributed nccl)" if backend == "nccl" else backend
+        gathered["note"] = ("torch.distributed.gather to rank 0, double-buffered: the gather of launch i overlaps "
+                            "launch i+1 (tinycarlo_amd/distributed.py)")
+
     n_resets = int(env._aux["spawn_cursor"].sum().item())
+    max_cursor = int(env._aux["spawn_cursor"].max().item())
     C = env.n_classes
     H, Wd = env.camera.resolution
     b_obs = 0 if w["no_obs"] else (C * H * Wd if w["fmt"] == "classes" else 3 * H * Wd)
     bytes_per_env_step = B_STATE + b_obs
-    step_s = ev_ms / 1e3 / K  # HIP events on the launch stream around the K timed steps (both kernels)
-    prof = env.profile_read()  # per-kernel HIP events sampled over the timed region
-    # One step = one fused kernel (tc_step_kernel: simulate + raster by the same wavefront), or, for large maps /
-    # TC_FUSE=0, two back-to-back kernels.  Either way the roofline unit is the step: SURVEY 8d's algorithmic
-    # bytes per env-step x envs per launch, divided by the (summed) kernel duration.
-    fused = bool(b_obs) and prof["raster_us"] < 0.25 * prof["simulate_us"]  # one tc_step_kernel launch per step
-    kname = "tc_step_kernel" if fused else ("tc_env_kernel+tc_raster_kernel" if b_obs else "tc_env_kernel")
-    kernel_s = (prof["simulate_us"] + (prof["raster_us"] if b_obs and not fused else 0.0)) * 1e-6
-    kbytes = bytes_per_env_step * n
-    achieved = kbytes / kernel_s / 1e9
-    traffic = pmc_traffic(args.workload, kname) if n == WORKLOADS[args.workload]["envs"] else None
+    step_s = ev_ms / 1e3 / K  # HIP events on the launch stream around the K timed steps
+    info = env.launch_info()  # what the library really launches (not guessed from timings)
+    kname = info["kernel"]
+    fused = info["fused"]
+    spl = M if M >= 1 else 1                       # steps per launch of the dominant kernel
+    full_launches = (K // M) if M >= 1 else K      # the sampled means below include a short last launch if K % M != 0
+    kernel_s = (prof["simulate_us"] + (prof["raster_us"] if b_obs and not fused else 0.0)) * 1e-6  # per LAUNCH
+    steps_in_sampled = K / max(n_l, 1)             # mean steps per launch over the timed region
+    kbytes = bytes_per_env_step * n * steps_in_sampled
+    achieved = kbytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(args.workload, kname, spl) if n == WORKLOADS[args.workload]["envs"] else (None, None)
     out = {
         "metric": "env-steps/sec (whole node)",
         "value": world * n * K / dt,
@@ -254,20 +334,28 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {n} envs/GPU, {w['map']} map, {H}x{Wd} '{w['fmt']}' obs, "
                                + ("kinematics+tracking+distances only (no_observation)" if w["no_obs"] else "with camera laneline raster"),
-                   "envs_per_gpu": n, "actions": "v~U(0.3,1) s~U(-1,1) maneuver~U{0..3}/64 steps, on device",
-                   "autoreset": True, "resets_in_run": n_resets, "gather_every_step": args.gather if world > 1 else "n/a", "gather_check_after_run": gathered_ok,
+                   "envs_per_gpu": n, "env_shard_of_rank0": [lo, hi] if rank == 0 else None,
+                   "steps_per_launch": M, "entry_point": "tc_step_multi" if M >= 1 else "tc_step",
+                   "observations": ("none" if w["no_obs"] else
+                                    (f"every step's frame stored to its own row of a [{M}, N, ...] rollout buffer" if M >= 1
+                                     else "every step's frame stored to the bound buffer")),
+                   "launches_timed": n_l, "preroll_steps": preroll,
+                   "actions": "v~U(0.3,1) s~U(-1,1) maneuver~U{0..3}/64 steps, on device",
+                   "autoreset": True, "spawn": "host queue (reference seed parity)", "resets_in_run": n_resets,
+                   "max_respawns_of_one_env": max_cursor, "spawn_queue_len": env.spawn_queue_len,
                    "lds_bytes_per_env": env.lds_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": kname, "kernel_us": kernel_s * 1e6, "algorithmic_bytes_per_launch": kbytes,
-                     "kernels_us": ({"tc_step_kernel": prof["simulate_us"]} if fused else
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": kname, "kernel_us": kernel_s * 1e6, "steps_per_launch": steps_in_sampled,
+                     "kernel_us_per_step": kernel_s * 1e6 / steps_in_sampled if steps_in_sampled else None,
+                     "algorithmic_bytes_per_launch": kbytes, "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                     "kernels_us": ({kname: prof["simulate_us"]} if (fused or not b_obs) else
                                     {"tc_env_kernel": prof["simulate_us"], "tc_raster_kernel": prof["raster_us"]}),
-                     "event_samples": prof["launches"],
-                     "step_us": step_s * 1e6, "step_algorithmic_bytes": bytes_per_env_step * n,
-                     "step_achieved_GBs": bytes_per_env_step * n / step_s / 1e9,
-                     "traffic_source": "profiles/r01 rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                       "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)" if traffic else None},
+                     "event_samples": prof["launches"], "full_launches": full_launches,
+                     "step_us": step_s * 1e6, "step_achieved_GBs": bytes_per_env_step * n / step_s / 1e9},
     }
+    if gathered is not None:
+        out["gathered"] = gathered
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(w, cfg, args.cpu_budget)

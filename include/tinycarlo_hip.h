@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 2
+#define TC_ABI_VERSION 3
 #define TC_MAX_LAYERS 16
 
 /* error codes */
@@ -73,6 +73,9 @@ extern "C" {
 #define TC_S_PICK_EMPTY 2    /* neighbour list made only of self-loops (ValueError at layer.py:123): truncated */
 #define TC_S_BAD_SPAWN 4     /* spawn node out of range or without out-edge: first spawnable node used instead */
 #define TC_S_NOT_RESET 8     /* tc_step on an env that was never reset: truncated, state untouched */
+#define TC_S_SPAWN_WRAPPED 16 /* TC_F_AUTORESET without TC_F_DEVICE_SPAWN: this re-spawn read spawn_queue past its end
+                                 (cursor >= spawn_queue_len, the queue is consumed cyclically): from here on the env
+                                 replays spawn nodes it already used -- refill the queue and clear spawn_cursor */
 
 /* Reward / termination terms: the wrappers of tinycarlo/wrapper/reward.py and termination.py, evaluated in the
  * epilogue of the step kernel in the order given (= the order the wrappers are stacked, innermost first; reward
@@ -224,6 +227,36 @@ int tc_reset(tc_env* env, const int32_t* spawn_nodes, const uint8_t* mask, uint3
  * dtype TC_F32 or TC_F64; maneuver: [N] in {0,1,2,3}. */
 int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const int32_t* maneuver, uint32_t flags,
             void* stream);
+
+/* K steps in ONE launch: the caller's `for k in range(K): env.step(action[k])` loop (env.py:115-147 called K times,
+ * e.g. examples/stanley_control.py:50-60 with the actions known in advance: action repeat, open-loop rollouts,
+ * scripted policies).  One wavefront stays with its env for all K steps -- envs are independent, so no grid-wide
+ * synchronisation exists between steps -- and keeps the env's state on chip in between.
+ *   car_control: [K][N][2], maneuver: [K][N] (step k uses row k).
+ *   Results are bit-identical to K calls of tc_step with the same flags: the bound buffers (tc_env_bind) hold the
+ *   state and the outputs of step K-1 afterwards; TC_F_AUTORESET re-spawns and fused terms (tc_env_set_terms) act
+ *   per step exactly as there.
+ *   rollout (may be NULL): per-step copies of the outputs a learner reads, each [K][N] (obs: [K][N][obs_bytes]) or
+ *   NULL.  With rollout->obs the observation of step k goes to rollout->obs[k] and the bound obs buffer is left
+ *   untouched; without it every step stores its observation into the bound buffer (which ends up holding the last).
+ * Maps that need the two-launch path (a lane-line layer with more than 576 nodes or edges, or TC_FUSE=0) are served
+ * by K pairs of launches from the host -- same results, no amortisation. */
+typedef struct {
+  uint8_t* obs;          /* [K][N][tc_env_obs_bytes] */
+  double* reward;        /* [K][N] */
+  uint8_t* terminated;   /* [K][N] */
+  uint8_t* truncated;    /* [K][N] */
+  double* cte;           /* [K][N] */
+  double* heading_error; /* [K][N] */
+} tc_rollout;
+int tc_step_multi(tc_env* env, const void* car_control, int32_t control_dtype, const int32_t* maneuver, int32_t n_steps,
+                  uint32_t flags, const tc_rollout* rollout, void* stream);
+
+/* What the library launches for a step with the current settings (for benchmark labels, not for control flow):
+ * fused = 1 when simulate + raster run as one kernel; kvar = register-cache variant of the simulate stage
+ * (5, 8, 9, 13); name receives the kernel symbol prefix ("tc_step_kernel", "tc_env_kernel+tc_raster_kernel" or
+ * "tc_env_kernel"), at most name_cap bytes including the terminator. */
+int tc_env_launch_info(const tc_env* env, uint32_t flags, int32_t* fused, int32_t* kvar, char* name, int32_t name_cap);
 
 /* Renderer.render_camera_frame_{rgb,classes} alone (renderer.py:36-51): rasterise caller-provided segment lists
  * into the bound observation tensor.  segments: device int32 [N][capacity][5] rows of (layer, x0, y0, x1, y1) --

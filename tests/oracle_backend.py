@@ -133,6 +133,18 @@ class OracleVecEnv(TinyCarloVecEnv):
         if self.noise[0] and not no_obs:
             self._apply_noise()
 
+    def step_multi(self, car_control, maneuver, rollout=None):
+        """TinyCarloVecEnv.step_multi on the oracle: K single steps, per-step outputs copied into the rollout rows;
+        with rollout["obs"] the bound observation buffer keeps its content (as tc_step_multi leaves it)."""
+        K = int(car_control.shape[0])
+        keep = self.out["obs"].clone() if (rollout and "obs" in rollout) else None
+        for k in range(K):
+            self.step_device(car_control[k], maneuver[k])
+            for key, t in (rollout or {}).items():
+                t[k].copy_(self.out[key])
+        if keep is not None:
+            self.out["obs"].copy_(keep)
+
     def render_current(self):
         self._push()
         import ctypes as C

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, what, q):
+def _worker(rank, world, port, total, what, mode, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -39,14 +39,30 @@ def _worker(rank, world, port, total, what, q):
     n = hi - lo
     env = OracleVecEnv(cfg, num_envs=n)
     env.reset(seed=shard_seed(100, rank, total // world))
-    g = RankGather(env, what=what)
     rng = np.random.default_rng(0)
     last = None
-    for t in range(6):
-        cc_all = np.stack([rng.uniform(0.3, 1, total), rng.uniform(-1, 1, total)], axis=1).astype(np.float32)
-        mn_all = rng.integers(0, 4, total).astype(np.int32)
-        env.step({"car_control": cc_all[lo:hi], "maneuver": mn_all[lo:hi]})
-        g.step()
+    if mode == "step":  # the caller steps, the gather stages env.out into its two slots
+        g = RankGather(env, what=what)
+        for t in range(6):
+            cc_all = np.stack([rng.uniform(0.3, 1, total), rng.uniform(-1, 1, total)], axis=1).astype(np.float32)
+            mn_all = rng.integers(0, 4, total).astype(np.int32)
+            env.step({"car_control": cc_all[lo:hi], "maneuver": mn_all[lo:hi]})
+            g.step()
+            if t in (2, 5):  # NOT after every step: two gathers are in flight while the env moves on
+                last = g.latest()
+    else:  # launch(): K steps per launch straight into the slot, gather of launch i overlapping launch i + 1
+        Kl = 2
+        g = RankGather(env, what=what, steps_per_launch=Kl)
+        acts = []
+        for t in range(6):
+            cc_all = np.stack([rng.uniform(0.3, 1, total), rng.uniform(-1, 1, total)], axis=1).astype(np.float32)
+            mn_all = rng.integers(0, 4, total).astype(np.int32)
+            acts.append((torch.from_numpy(cc_all[lo:hi].copy()), torch.from_numpy(mn_all[lo:hi].copy())))
+        seen = []
+        for i in range(0, 5, Kl):  # launches of 2, 2 and a short one of 1 ... then the 6th step alone
+            rows = min(Kl, 5 - i)
+            g.launch(torch.stack([a[0] for a in acts[i:i + rows]]), torch.stack([a[1] for a in acts[i:i + rows]]))
+        g.launch(acts[5][0], acts[5][1])  # [N, 2] / [N] form
         last = g.latest()
     if rank == 0:
         # reference: one unsharded env over all `total` envs with the same global seeds and actions
@@ -67,12 +83,15 @@ def _worker(rank, world, port, total, what, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["step", "launch"])
 @pytest.mark.parametrize("what", ["flags", "obs"])
-def test_sharded_envs_gather_to_rank0(what):
+def test_sharded_envs_gather_to_rank0(what, mode):
+    """2 ranks x 4 envs, 6 steps, rank 0 compares what it gathered with one unsharded 8-env run: post-hoc staging
+    (`step`) and the double-buffered K-step launches (`launch`, incl. a short last launch and the one-step form)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 8, what, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 8, what, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -86,7 +86,9 @@ struct CarState {
 // ------------------------------------------------------------------ scalar helpers
 __device__ inline double d_clip_angle(double a) {  // helper.py:11-19 (bounded, see oracle)
   int guard = 0;
+#pragma nounroll
   while (a > TC_PI && guard++ < 64) a -= 2 * TC_PI;
+#pragma nounroll
   while (a < -TC_PI && guard++ < 128) a += 2 * TC_PI;
   return a;
 }
@@ -234,8 +236,7 @@ __device__ inline int d_pick_prev_f(const DevMap& m, const LpNode& A, int node_i
 
 // layer.py:59-74 over the lanepath, all 64 lanes cooperating; returns edge index or -1
 __device__ inline int d_nearest_edge_with_orientation(const DevMap& m, double px, double py, double orientation,
-                                                      double margin_deg) {
-  const int tid = threadIdx.x;
+                                                      double margin_deg, const int tid) {
   double lim = d_radians(margin_deg);
   int best = -1;
   double bd = 0;
@@ -287,14 +288,14 @@ struct PathInfo {
 };
 
 // car.py:127-148
-__device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuver, int& status, PathInfo& pi) {
+__device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuver, int& status, PathInfo& pi, const int tid) {
   double fx = s.front_x, fy = s.front_y;
   int e0 = s.lp[0], e1 = s.lp[1];
   const LpNode N0 = m.lp_fat[e0], N1 = m.lp_fat[e1];
   double mdir = d_clip_angle(d_edge_ori_f(m, N0, e0, e1) + (maneuver * TC_PI) / 2);
   int ne0, ne1;
   if (maneuver == 2 && s.last_maneuver != 2) {  // wave-uniform branch
-    int e = d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0);
+    int e = d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0, tid);
     mdir = d_clip_angle(mdir + TC_PI);
     if (e < 0) {
       status |= 1;  // TC_S_UTURN_NO_EDGE
@@ -359,8 +360,10 @@ __device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuv
 }
 
 // car.py:70-125; returns truncated
+// have_trig: s.cth / s.sth already hold cos / sin of s.theta (left there by the front-axle update of the previous step
+// of the same launch): the same function of the same argument, so reusing them changes no bit
 __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, double v_in, double s_in, int maneuver,
-                                 int& status, PathInfo& pi) {
+                                 int& status, PathInfo& pi, bool have_trig, const int tid) {
   double dt = c.T;
   double nv = v_in * c.max_velocity;
   if (c.has_max_acceleration)
@@ -369,7 +372,14 @@ __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, 
   double ns = s_in * c.max_steering_angle;
   if (c.has_steering_speed) ns = d_np_clip(ns, s.steering - c.steering_speed * dt, s.steering + c.steering_speed * dt);
   s.steering = ns;
-  double vxn = tc_cos(s.theta), vyn = tc_sin(s.theta);
+  double vxn, vyn;
+  if (have_trig) {
+    vxn = s.cth;
+    vyn = s.sth;
+  } else {
+    vxn = tc_cos(s.theta);
+    vyn = tc_sin(s.theta);
+  }
   if (tc_fabs(s.steering) < 0.0001) {
     s.radius = 0;
     s.x = s.x + s.velocity * vxn * dt;
@@ -379,7 +389,6 @@ __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, 
     s.sth = vyn;
     s.front_x = s.x + c.wheelbase * vxn;
     s.front_y = s.y + c.wheelbase * vyn;
-    return d_find_local_path(m, s, maneuver, status, pi);
   } else {
     s.radius = c.wheelbase / tc_tan(d_radians(s.steering));
     double ang_vel = s.velocity / s.radius;
@@ -387,8 +396,8 @@ __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, 
     double nx = vyn, ny = -vxn;
     double tx = nx * s.radius, ty = ny * s.radius;
     double cd = tc_cos(dyaw), sd = tc_sin(dyaw);
-    double r0 = cd * tx + (-sd) * ty;
-    double r1 = sd * tx + cd * ty;
+    double r0 = __builtin_fma(cd, tx, (-sd) * ty);  // numpy's dgemv association, see oracle/tc_oracle.c
+    double r1 = __builtin_fma(sd, tx, cd * ty);
     s.x = s.x - tx + r0;
     s.y = s.y - ty + r1;
     s.theta += dyaw;
@@ -396,22 +405,24 @@ __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, 
       s.theta -= 2 * TC_PI;
     else if (s.theta < -TC_PI)
       s.theta += 2 * TC_PI;
+    d_update_front(c, s);
   }
-  d_update_front(c, s);
-  return d_find_local_path(m, s, maneuver, status, pi);
+  return d_find_local_path(m, s, maneuver, status, pi, tid);  // ONE call site: the function is ~2 k instructions inlined
 }
 
 // ------------------------------------------------------------------ camera.py helpers
-// C[i][j] = sum_t A[i][t] * B[t][j], t ascending (same association as the oracle)
+// C[i][j] = one chain of fused multiply-adds over ascending t from a zero accumulator: the association of numpy's
+// `A @ B` (OpenBLAS dgemm on x86-64 with FMA) that the reference's camera runs on -- see matmul() in oracle/tc_oracle.c.
+// The fma here is an explicit operation of the algorithm, not a contraction (the library is built -ffp-contract=off).
 template <int N, int K, int P>
 __device__ inline void d_matmul(const double* A, const double* B, double* C) {
 #pragma unroll
   for (int i = 0; i < N; i++)
 #pragma unroll
     for (int j = 0; j < P; j++) {
-      double acc = A[i * K] * B[j];
+      double acc = 0.0;
 #pragma unroll
-      for (int t = 1; t < K; t++) acc += A[i * K + t] * B[t * P + j];
+      for (int t = 0; t < K; t++) acc = __builtin_fma(A[i * K + t], B[t * P + j], acc);
       C[i * P + j] = acc;
     }
 }

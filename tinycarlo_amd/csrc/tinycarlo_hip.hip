@@ -70,6 +70,34 @@ __device__ long long* tc_tstamp = nullptr;  // [N][32]
 struct LdsLayout {
   int off_p, off_flg, off_list, off_cnt;
   int total;
+  int off_live;  // tc_step_multi: the env's state between two steps (beyond both stages' buffers, never aliased)
+};
+
+// The env's state and step outputs live in this LDS record for the whole launch: live_in() fills it from the caller's
+// buffers, every step reads and rewrites it (one wavefront, program order), live_out() stores it back.  The step body
+// therefore has ONE form whether it is the only step of a launch (tc_step) or one of many (tc_step_multi), and the
+// raster stage keeps none of it in registers.
+struct LiveLds {
+  double d[10];  // x, y, theta, velocity, steering, radius, front_x, front_y, cos(theta), sin(theta)
+  double cte, he, reward;
+  double dist[TC_MAX_LAYERS];
+  int lp[8];
+  int lp_len, last_maneuver;
+  int have_trig;    // d[8], d[9] hold cos / sin of d[2] (set by every update of the front axle)
+  int needs_reset;  // TC_F_AUTORESET: re-spawn at the start of the next step
+  int cursor;       // spawn_cursor: re-spawns of this env so far
+  int cursor0;      // its value in the caller's buffer (stored back only when it changed)
+  int trunc, status, terminated, pad[3];
+  int cnt[TC_MAX_TERMS];  // steps_true of the consecutive-step terms
+  int ne[TC_MAX_LAYERS];
+};
+#define TC_LIVE_BYTES 416
+static_assert(sizeof(LiveLds) <= TC_LIVE_BYTES, "LiveLds must fit its LDS slot");
+
+// per-step rollout outputs of tc_step_multi, already advanced to the current step (each [N] or NULL)
+struct RollStep {
+  double *reward, *cte, *heading_error;
+  unsigned char *terminated, *truncated;
 };
 
 struct KArgs {
@@ -112,6 +140,14 @@ __device__ inline double d_linear_reward(double x, double max_x, double max_rewa
 __device__ __forceinline__ double d_readlane(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// wave-uniform value as something the compiler knows to be uniform (first active lane's copy, held in SGPRs)
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
 
@@ -177,19 +213,19 @@ struct MapCache {
 
 // slot k of lane tid <-> node (edge) base + k*64 + tid, valid below `end`
 template <int K>
-__device__ inline void cache_nodes(MapCache<K>& c, const DevMap& m, int base, int end) {
+__device__ inline void cache_nodes(MapCache<K>& c, const DevMap& m, int base, int end, int tid) {
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    const int i = base + k * TC_NT + threadIdx.x;
+    const int i = base + k * TC_NT + tid;
     c.nd[k] = i < end ? m.nodes[i] : make_double2(0.0, 0.0);
   }
 }
 // node ids are stored relative to `nbase` (the first node of the camera group; 0 for whole-map use)
 template <int K>
-__device__ inline void cache_edges(MapCache<K>& c, const DevMap& m, int base, int end, int nbase) {
+__device__ inline void cache_edges(MapCache<K>& c, const DevMap& m, int base, int end, int nbase, int tid) {
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    const int e = base + k * TC_NT + threadIdx.x;
+    const int e = base + k * TC_NT + tid;
     int2 ed = e < end ? m.edges_g[e] : make_int2(nbase, nbase);
     c.ed[k] = make_int2(ed.x - nbase, ed.y - nbase);
   }
@@ -205,10 +241,10 @@ __device__ inline void cache_edges(MapCache<K>& c, const DevMap& m, int base, in
 template <int K>
 __device__ inline void cam_fixup_pass(MapCache<K>& mc, const DevMap& m, bool reload, int ge0, int ne, int gn0, int nwin,
                                       double* Px, double* Py, double* Pz, unsigned char* flg, int bit, bool target_e0,
-                                      double tz, int* list, int* cnt) {
-  const int tid = threadIdx.x;  // *cnt was zeroed (and a barrier passed) before the call
+                                      double tz, int* list, int* cnt, int tid) {
+  // *cnt was zeroed (and a barrier passed) before the call
   for (int w = 0; w < nwin; w++) {
-    if (reload) cache_edges(mc, m, ge0 + w * K * TC_NT, ge0 + ne, gn0);
+    if (reload) cache_edges(mc, m, ge0 + w * K * TC_NT, ge0 + ne, gn0, tid);
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const int e = (w * K + k) * TC_NT + tid;
@@ -289,8 +325,7 @@ __device__ inline int2 cam_project(const double* K, double X, double Y, double Z
   return make_int2(d_np_int32(u), d_np_int32(v));
 }
 
-__device__ inline int wave_incl_scan(int v) {
-  const int lane = threadIdx.x;
+__device__ inline int wave_incl_scan(int v, int lane) {
 #pragma unroll
   for (int off = 1; off < TC_NT; off <<= 1) {
     int o = __shfl_up(v, off);
@@ -299,18 +334,114 @@ __device__ inline int wave_incl_scan(int v) {
   return v;
 }
 
+// Caller's buffers -> LiveLds, one item per lane (one vector-memory round trip for the ~30 scalars of an env).
+__device__ __forceinline__ void live_in(const KArgs& a, unsigned char* smem, int env, int mode, unsigned int flags) {
+  const int tid = threadIdx.x;
+  const tc_buffers& b = a.b;
+  LiveLds* lv = (LiveLds*)(smem + a.lds.off_live);
+  if (tid < 8) {
+    const double* p = b.x;
+    p = tid == 1 ? b.y : p;
+    p = tid == 2 ? b.theta : p;
+    p = tid == 3 ? b.velocity : p;
+    p = tid == 4 ? b.steering : p;
+    p = tid == 5 ? b.radius : p;
+    p = tid == 6 ? b.front_x : p;
+    p = tid == 7 ? b.front_y : p;
+    lv->d[tid] = p[env];
+  } else if (tid < 16) {
+    lv->lp[tid - 8] = b.local_path[env * 8 + (tid - 8)];
+  } else if (tid == 16) {
+    lv->lp_len = b.lp_len[env];
+  } else if (tid == 17) {
+    lv->last_maneuver = b.last_maneuver[env];
+  } else if (tid == 18) {
+    lv->needs_reset = (mode == MODE_STEP && (flags & TC_F_AUTORESET)) ? b.needs_reset[env] : 0;
+  } else if (tid == 19) {
+    const int c = (mode == MODE_STEP && (flags & TC_F_AUTORESET)) ? b.spawn_cursor[env] : 0;
+    lv->cursor = c;
+    lv->cursor0 = c;
+  } else if (tid < 28) {
+    const int t = tid - 20;
+    lv->cnt[t] = (a.n_terms > 0 && a.term_counters) ? a.term_counters[(size_t)env * TC_MAX_TERMS + t] : 0;
+  } else if (tid == 28) {
+    lv->d[8] = 0;
+    lv->d[9] = 0;
+    lv->have_trig = 0;
+  }
+  __syncthreads();
+}
+
+// LiveLds -> caller's buffers after the last step of the launch (not for MODE_RENDER, which changes nothing).
+__device__ __forceinline__ void live_out(const KArgs& a, unsigned char* smem, int env) {
+  const int tid = threadIdx.x;
+  const tc_buffers& b = a.b;
+  const LiveLds* lv = (const LiveLds*)(smem + a.lds.off_live);
+  const int C = a.m.C;
+  __syncthreads();
+  if (tid < 8) {
+    double* p = b.x;
+    p = tid == 1 ? b.y : p;
+    p = tid == 2 ? b.theta : p;
+    p = tid == 3 ? b.velocity : p;
+    p = tid == 4 ? b.steering : p;
+    p = tid == 5 ? b.radius : p;
+    p = tid == 6 ? b.front_x : p;
+    p = tid == 7 ? b.front_y : p;
+    p[env] = lv->d[tid];
+  } else if (tid < 16) {
+    b.local_path[env * 8 + (tid - 8)] = lv->lp[tid - 8];
+  } else if (tid == 16) {
+    b.lp_len[env] = lv->lp_len;
+  } else if (tid == 17) {
+    b.last_maneuver[env] = lv->last_maneuver;
+  } else if (tid == 18) {
+    if (b.needs_reset) b.needs_reset[env] = (unsigned char)lv->needs_reset;
+  } else if (tid == 19) {
+    if (lv->cursor != lv->cursor0) b.spawn_cursor[env] = lv->cursor;
+  } else if (tid < 28) {
+    const int t = tid - 20;
+    if (a.term_counters && t < a.n_terms) a.term_counters[(size_t)env * TC_MAX_TERMS + t] = lv->cnt[t];
+  } else if (tid == 28) {
+    b.cte[env] = lv->cte;
+  } else if (tid == 29) {
+    b.heading_error[env] = lv->he;
+  } else if (tid == 30) {
+    b.reward[env] = lv->reward;
+  } else if (tid == 31) {
+    b.terminated[env] = (unsigned char)lv->terminated;
+  } else if (tid == 32) {
+    b.truncated[env] = (unsigned char)lv->trunc;
+  } else if (tid == 33) {
+    b.status[env] = lv->status;
+  } else if (tid < 34 + TC_MAX_LAYERS - 4) {  // lanes 34..45: layers 0..11
+    const int l = tid - 34;
+    if (l < C) {
+      b.laneline_distances[(size_t)env * C + l] = lv->dist[l];
+      b.nearest_edge[(size_t)env * C + l] = lv->ne[l];
+    }
+  } else if (tid < 50) {  // lanes 46..49: layers 12..15
+    const int l = tid - 34;
+    if (l < C) {
+      b.laneline_distances[(size_t)env * C + l] = lv->dist[l];
+      b.nearest_edge[(size_t)env * C + l] = lv->ne[l];
+    }
+  }
+}
+
 #ifndef TC_MIN_WAVES
 #define TC_MIN_WAVES 4
 #endif
 // Stage 1 (simulate) for one env by one wavefront.  Returns false when nothing is to be rasterised for this env.
 // always inlined: out of line, `a` would be a pointer into private memory and the whole kernel-argument struct
 // (~1 KB) would be copied to scratch by every lane (the inliner's cost threshold is close: measured 47.9 k vs 47.6 k)
+// One step of one env: reads and rewrites the env's LiveLds record; the caller's buffers are only touched by live_in /
+// live_out (and the per-step rollout rows of `roll`).
 template <int K>
-__device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, int env, int mode, const void* car_control, int cdtype,
+__device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, int env, int mode,
+                                const void* car_control, int cdtype,
                                 const int* maneuver, const int* spawn_nodes, const unsigned char* mask,
-                                unsigned int flags) {
-  const int tid = threadIdx.x;
-  if (mode == MODE_RESET && mask && !mask[env]) return false;  // whole workgroup skips: no barrier below is reached
+                                unsigned int flags, const RollStep& roll, const int tid) {
 
   TSTAMP(0);
   const DevMap& m = a.m;
@@ -320,8 +451,8 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
   const bool single = a.n_grp == 1 && nwin_n <= 1 && nwin_e <= 1;
   MapCache<K> mc;
   if (single) {
-    cache_nodes(mc, m, 0, m.total_nodes);
-    cache_edges(mc, m, 0, m.total_edges, 0);
+    cache_nodes(mc, m, 0, m.total_nodes, tid);
+    cache_edges(mc, m, 0, m.total_edges, 0, tid);
   }
   double* Px = (double*)(smem + a.lds.off_p);
   double* Py = Px + a.cap_nodes;
@@ -331,27 +462,31 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
   int* list = (int*)(smem + a.lds.off_list);
   int* cnt = (int*)(smem + a.lds.off_cnt);
 
-  // ---- state (wave-uniform loads)
+  // ---- state: all lanes read the same LDS words (broadcast)
+  LiveLds* lv = (LiveLds*)(smem + a.lds.off_live);
+  // (readfirstlane: the values are wave-uniform, and the compiler has to KNOW it -- read straight from LDS they count
+  // as divergent, every branch of the scalar phases below becomes an exec-mask region and the kernel triples in size)
   CarState s;
-  s.x = b.x[env];
-  s.y = b.y[env];
-  s.theta = b.theta[env];
-  s.velocity = b.velocity[env];
-  s.steering = b.steering[env];
-  s.radius = b.radius[env];
-  s.front_x = b.front_x[env];
-  s.front_y = b.front_y[env];
+  s.x = uni_d(lv->d[0]);
+  s.y = uni_d(lv->d[1]);
+  s.theta = uni_d(lv->d[2]);
+  s.velocity = uni_d(lv->d[3]);
+  s.steering = uni_d(lv->d[4]);
+  s.radius = uni_d(lv->d[5]);
+  s.front_x = uni_d(lv->d[6]);
+  s.front_y = uni_d(lv->d[7]);
+  s.cth = uni_d(lv->d[8]);
+  s.sth = uni_d(lv->d[9]);
 #pragma unroll
-  for (int i = 0; i < 8; i++) s.lp[i] = b.local_path[env * 8 + i];
-  s.lp_len = b.lp_len[env];
-  s.last_maneuver = b.last_maneuver[env];
-
-  // steps_true of the consecutive-step terms: one coalesced 32-byte load now, hidden behind phase A
-  int my_cnt = 0;
-  if (a.n_terms > 0 && a.term_counters && tid < TC_MAX_TERMS) my_cnt = a.term_counters[(size_t)env * TC_MAX_TERMS + tid];
+  for (int i = 0; i < 8; i++) s.lp[i] = uni_i(lv->lp[i]);
+  s.lp_len = uni_i(lv->lp_len);
+  s.last_maneuver = uni_i(lv->last_maneuver);
+  bool have_trig = uni_i(lv->have_trig) != 0;  // s.cth / s.sth hold cos / sin of the current heading
+  const int nr = uni_i(lv->needs_reset);
+  int cursor = uni_i(lv->cursor);
+  int my_cnt = tid < TC_MAX_TERMS ? lv->cnt[tid] : 0;  // lane t: steps_true of term slot t
 
   int status = 0, trunc = 0;
-  bool have_trig = false;  // s.cth / s.sth hold cos / sin of the current heading
   PathInfo pinfo;
   pinfo.ax = pinfo.ay = pinfo.bx = pinfo.by = pinfo.ori = 0;
   pinfo.valid = 0;
@@ -361,17 +496,19 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     fresh = true;
     have_trig = true;
   } else if (mode == MODE_STEP) {
-    if ((flags & TC_F_AUTORESET) && b.needs_reset[env]) {
-      int cur = b.spawn_cursor[env];
+    if ((flags & TC_F_AUTORESET) && nr) {
+      const int cur = cursor;
       int node;
-      if ((flags & TC_F_DEVICE_SPAWN) && a.spawn_n > 0)
+      if ((flags & TC_F_DEVICE_SPAWN) && a.spawn_n > 0) {
         node = a.spawn_tab[tc_spawn_index(a.spawn_seed, (uint32_t)env, (uint32_t)cur, (uint32_t)a.spawn_n)];
-      else
+      } else {
+        if ((unsigned)cur >= (unsigned)b.spawn_queue_len) status |= TC_S_SPAWN_WRAPPED;  // replaying the queue
         node = b.spawn_queue[(size_t)env * b.spawn_queue_len + ((unsigned)cur % (unsigned)b.spawn_queue_len)];
+      }
       d_reset(m, a.car, s, checked_spawn(m, node, status));
       fresh = true;
       have_trig = true;
-      if (tid == 0) b.spawn_cursor[env] = cur + 1;
+      cursor = cur + 1;
     } else if ((unsigned)s.lp[0] >= (unsigned)m.lpN || (unsigned)s.lp[1] >= (unsigned)m.lpN) {
       status |= TC_S_NOT_RESET;  // stepping an env that was never reset: no valid lanepath edge to index with
       trunc = 1;
@@ -386,7 +523,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
       }
       v = d_np_clip(v, -1.0, 1.0);  // env.py:118
       st = d_np_clip(st, -1.0, 1.0);
-      trunc = d_car_step(m, a.car, s, v, st, maneuver[env], status, pinfo);
+      trunc = d_car_step(m, a.car, s, v, st, maneuver[env], status, pinfo, have_trig, tid);
       have_trig = true;
     }
   }
@@ -417,31 +554,40 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     }
     const bool late = a.n_terms > 0;  // reward / terminated depend on phase B: written after it
     if (tid == 0) {
-      b.x[env] = s.x;
-      b.y[env] = s.y;
-      b.theta[env] = s.theta;
-      b.velocity[env] = s.velocity;
-      b.steering[env] = s.steering;
-      b.radius[env] = s.radius;
-      b.front_x[env] = s.front_x;
-      b.front_y[env] = s.front_y;
-      b.lp_len[env] = s.lp_len;
-      b.last_maneuver[env] = s.last_maneuver;
-      b.cte[env] = cte;
-      b.heading_error[env] = he;
-      b.truncated[env] = (unsigned char)trunc;
-      b.status[env] = status;
+      lv->d[0] = s.x;
+      lv->d[1] = s.y;
+      lv->d[2] = s.theta;
+      lv->d[3] = s.velocity;
+      lv->d[4] = s.steering;
+      lv->d[5] = s.radius;
+      lv->d[6] = s.front_x;
+      lv->d[7] = s.front_y;
+      lv->d[8] = s.cth;
+      lv->d[9] = s.sth;
+      lv->lp_len = s.lp_len;
+      lv->last_maneuver = s.last_maneuver;
+      lv->have_trig = have_trig ? 1 : 0;
+      lv->cursor = cursor;
+      lv->cte = cte;
+      lv->he = he;
+      lv->trunc = trunc;
+      lv->status = status;
+      if (roll.cte) roll.cte[env] = cte;
+      if (roll.heading_error) roll.heading_error[env] = he;
+      if (roll.truncated) roll.truncated[env] = (unsigned char)trunc;
       if (!late) {
-        b.reward[env] = reward;
-        b.terminated[env] = (unsigned char)terminated;
-        if (b.needs_reset) b.needs_reset[env] = (flags & TC_F_AUTORESET) ? (unsigned char)(terminated || trunc) : 0;
+        lv->reward = reward;
+        lv->terminated = terminated;
+        lv->needs_reset = (flags & TC_F_AUTORESET) ? (terminated || trunc) : 0;
+        if (roll.reward) roll.reward[env] = reward;
+        if (roll.terminated) roll.terminated[env] = (unsigned char)terminated;
       }
     }
     if (tid < 8) {  // register-resident select (a runtime-indexed s.lp[tid] would live in scratch)
       int v = s.lp[0];
 #pragma unroll
       for (int i = 1; i < 8; i++) v = tid == i ? s.lp[i] : v;
-      b.local_path[env * 8 + tid] = v;
+      lv->lp[tid] = v;
     }
 
     TSTAMP(2);
@@ -450,7 +596,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     double dist_l = 0;  // lane l < C: distance to lane-line layer l (0 while the info is empty, car.py:47-51)
     if (have_info && !(flags & DBG_SKIP_DIST)) {
       for (int w = 0; w < nwin_n; w++) {
-        if (!single) cache_nodes(mc, m, w * K * TC_NT, m.total_nodes);
+        if (!single) cache_nodes(mc, m, w * K * TC_NT, m.total_nodes, tid);
 #pragma unroll
         for (int k = 0; k < K; k++) {
           const int i = (w * K + k) * TC_NT + tid;
@@ -471,7 +617,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
           const int w0 = w * K * TC_NT;
           if (w0 >= eend || w0 + K * TC_NT <= eo) continue;  // no edge of this layer in the window
           if (!single && w != cur_w) {
-            cache_edges(mc, m, w0, m.total_edges, 0);
+            cache_edges(mc, m, w0, m.total_edges, 0, tid);
             cur_w = w;
           }
 #pragma unroll
@@ -504,26 +650,28 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
             dist_l = db < da ? db : da;
           }
         }
-        b.laneline_distances[(size_t)env * C + l] = dist_l;
-        b.nearest_edge[(size_t)env * C + l] = my_e;
+        lv->dist[l] = dist_l;
+        lv->ne[l] = my_e;
       }
       TSTAMP(16);
       __syncthreads();  // dn aliases the camera's node buffer
     } else if (tid < C) {
-      b.laneline_distances[(size_t)env * C + tid] = 0;
-      b.nearest_edge[(size_t)env * C + tid] = -1;
+      lv->dist[tid] = 0;
+      lv->ne[tid] = -1;
     }
     if (late) {
       // a re-spawned env did not go through Wrapper.step (the reference's reset() bypasses the wrappers)
       if (!fresh) {
         d_apply_terms(a.terms, a.n_terms, my_cnt, a.car.track_width, tid, C, cte, have_info ? s.velocity : 0.0, dist_l,
                       reward, terminated);
-        if (a.term_counters && tid < a.n_terms) a.term_counters[(size_t)env * TC_MAX_TERMS + tid] = my_cnt;
+        if (tid < TC_MAX_TERMS) lv->cnt[tid] = my_cnt;
       }
       if (tid == 0) {
-        b.reward[env] = reward;
-        b.terminated[env] = (unsigned char)terminated;
-        if (b.needs_reset) b.needs_reset[env] = (flags & TC_F_AUTORESET) ? (unsigned char)(terminated || trunc) : 0;
+        lv->reward = reward;
+        lv->terminated = terminated;
+        lv->needs_reset = (flags & TC_F_AUTORESET) ? (terminated || trunc) : 0;
+        if (roll.reward) roll.reward[env] = reward;
+        if (roll.terminated) roll.terminated[env] = (unsigned char)terminated;
       }
     }
   }
@@ -573,12 +721,12 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     const bool one = nwn <= 1 && nwe <= 1;  // the group fits the register cache: loaded once, serves every pass
     const bool reload = !one;
     if (one && !single) {
-      cache_nodes(mc, m, gn0, gn0 + nn);
-      cache_edges(mc, m, ge0, ge0 + ne, gn0);
+      cache_nodes(mc, m, gn0, gn0 + nn, tid);
+      cache_edges(mc, m, ge0, ge0 + ne, gn0, tid);
     }
     if (tid < 5) cnt[tid] = 0;
     for (int w = 0; w < nwn; w++) {  // camera.py:124-131
-      if (reload) cache_nodes(mc, m, gn0 + w * K * TC_NT, gn0 + nn);
+      if (reload) cache_nodes(mc, m, gn0 + w * K * TC_NT, gn0 + nn, tid);
 #pragma unroll
       for (int k = 0; k < K; k++) {
         const int i = (w * K + k) * TC_NT + tid;
@@ -595,16 +743,16 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     }
     __syncthreads();
     TSTAMP(4);
-    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, true, -0.0000001, list, cnt + 0);   // camera.py:71-74
+    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, true, -0.0000001, list, cnt + 0, tid);   // camera.py:71-74
     TSTAMP(17);
-    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, false, -0.0000001, list, cnt + 1);  // camera.py:75-77
+    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, false, -0.0000001, list, cnt + 1, tid);  // camera.py:75-77
     TSTAMP(18);
     for (int i = tid; i < nn; i += TC_NT)
       if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
     __syncthreads();
-    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, true, -cam.max_range, list, cnt + 2);   // camera.py:81-83
+    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, true, -cam.max_range, list, cnt + 2, tid);   // camera.py:81-83
     TSTAMP(19);
-    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, false, -cam.max_range, list, cnt + 3);  // camera.py:84-86
+    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, false, -cam.max_range, list, cnt + 3, tid);  // camera.py:84-86
     TSTAMP(5);
     // Only nodes in front AND in range can be "visible" (camera.py:92-93): compact them so the two f64
     // divisions of the projection are paid for those nodes only.
@@ -623,7 +771,7 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     __syncthreads();
     TSTAMP(6);
     for (int w = 0; w < nwe; w++) {  // camera.py:95
-      if (reload) cache_edges(mc, m, ge0 + w * K * TC_NT, ge0 + ne, gn0);
+      if (reload) cache_edges(mc, m, ge0 + w * K * TC_NT, ge0 + ne, gn0, tid);
 #pragma unroll
       for (int k = 0; k < K; k++) {
         const int e = (w * K + k) * TC_NT + tid;
@@ -654,14 +802,19 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
   return true;
 }
 
-template <int K>
-__global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) void tc_env_kernel(KArgs a, int mode, const void* car_control, int cdtype,
-                                                       const int* maneuver, const int* spawn_nodes,
-                                                       const unsigned char* mask, unsigned int flags) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int env = a.env0 + blockIdx.x;
-  if (env >= a.N) return;
-  sim_body<K>(a, smem, env, mode, car_control, cdtype, maneuver, spawn_nodes, mask, flags);
+// Step k of a launch reads row k of the action arrays and writes row k of the rollout arrays ([nsteps][N] each).
+struct MultiArgs {
+  int nsteps;
+  tc_rollout roll;
+};
+__device__ __forceinline__ RollStep roll_at(const tc_rollout& r, size_t row0) {
+  RollStep q;
+  q.reward = r.reward ? r.reward + row0 : nullptr;
+  q.cte = r.cte ? r.cte + row0 : nullptr;
+  q.heading_error = r.heading_error ? r.heading_error + row0 : nullptr;
+  q.terminated = r.terminated ? r.terminated + row0 : nullptr;
+  q.truncated = r.truncated ? r.truncated + row0 : nullptr;
+  return q;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -690,8 +843,8 @@ struct RArgs {
 #define TC_RASTER_WAVES 4
 #endif
 template <bool THICK, int FMT>
-__device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem, int env) {
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem, int env, unsigned char* obs_base,
+                                            const int tid) {
   const RCam& cam = a.cam;
   unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
   const int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;
@@ -703,7 +856,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
   for (int off = 32; off > 0; off >>= 1) used_layers |= __shfl_xor(used_layers, off);
 
   const int H = cam.H, W = cam.W, wpr = cam.wpr, C = a.C;
-  unsigned char* out = a.obs + (size_t)env * ((size_t)H * W * (FMT == TC_FMT_CLASSES ? C : 3));
+  unsigned char* out = obs_base + (size_t)env * ((size_t)H * W * (FMT == TC_FMT_CLASSES ? C : 3));
   int* lt = (int*)(smem + R_OFF_TAB);     // [RB*4][5] outline-edge parameters
   int* lc = lt + RB * 4 * 5;              // [RB*4] chunks per outline edge, then exclusive prefix
   int* fl = lc + RB * 4;                  // [RB] first fill row of the segment in this band
@@ -753,7 +906,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
               okq = 1;
               dpx = (int)(qx0 - (long long)sg[1] * TC_XY_ONE);
               dpy = (int)(qy0 - (long long)sg[2] * TC_XY_ONE);
-              int hi;
+              int hi = -1;
               if (!(a.flags & DBG_SKIP_EVENTS))
               np = r_fill_events(W, H, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, fpy + 4 * tid, fpv + 4 * tid, wm, lo,
                                  hi);
@@ -814,10 +967,10 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
         int tot_l, tot_f;
         {  // exclusive prefix sums (RB*4 = 2 entries per lane; RB entries on the low lanes)
           int v0 = lc[2 * tid], v1 = lc[2 * tid + 1];
-          int inc = wave_incl_scan(v0 + v1);
+          int inc = wave_incl_scan(v0 + v1, tid);
           tot_l = __shfl(inc, TC_NT - 1);
           int f = tid < RB ? fc[tid] : 0;
-          int finc = wave_incl_scan(f);
+          int finc = wave_incl_scan(f, tid);
           tot_f = __shfl(finc, TC_NT - 1);
           lc[2 * tid] = inc - v0 - v1;  // each lane rewrites only the entries it read
           lc[2 * tid + 1] = inc - v1;
@@ -991,7 +1144,7 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
   const int env = a.env0 + blockIdx.x;
   if (env >= a.N) return;
   if (a.mask && !a.mask[env]) return;
-  raster_body<THICK, FMT>(a, smem, env);
+  raster_body<THICK, FMT>(a, smem, env, a.obs, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1156,25 +1309,106 @@ __global__ __launch_bounds__(TC_NT) void tc_noise_kernel(NArgs a) {
   }
 }
 
-// Both stages in one launch: the same wavefront simulates its env and then rasterises it.  Saves one kernel
-// boundary (launch gap + one ramp-up / drain of the whole grid) per step.
-template <int K, bool THICK, int FMT>
-__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_kernel(KArgs a, RArgs r, int mode, const void* car_control,
-                                                                     int cdtype, const int* maneuver, const int* spawn_nodes,
-                                                                     const unsigned char* mask, unsigned int flags) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int env = a.env0 + blockIdx.x;
-  if (env >= a.N) return;
-  if (!sim_body<K>(a, smem, env, mode, car_control, cdtype, maneuver, spawn_nodes, mask, flags)) return;
-  __syncthreads();  // draw list + count written by this wavefront are visible to it (vmcnt(0) + barrier)
-  raster_body<THICK, FMT>(r, smem, env);
+// Everything a launch is given, as ONE kernel parameter (so that it sits at offset 0 of the kernarg segment).
+struct StepArgs {
+  KArgs a;
+  RArgs r;
+  MultiArgs ma;
+  int mode, cdtype;
+  unsigned int flags;
+  const void* car_control;
+  const int* maneuver;
+  const int* spawn_nodes;
+  const unsigned char* mask;
+};
+
+// The launch arguments, read through a pointer the optimiser cannot see through.  Inside the step loop of tc_step_multi
+// every argument (and every address computed from one) is loop invariant; LLVM hoists all of them out of the loop and
+// keeps them alive across the whole ~20 k-instruction body -- measured: 817 SGPRs spilled into VGPR lanes, which in turn
+// pushed 223 VGPRs to scratch.  Re-deriving the pointer per step (an empty asm the compiler must assume changes it)
+// makes each use reload its argument with a scalar load from the constant address space where it needs it, exactly as
+// in a single-step kernel.
+// The lane id, likewise: everything computed from it (lane predicates, LDS addresses) is loop invariant too and was
+// hoisted and then spilled (-mllvm -disable-machine-licm in the Makefile does the same for the constants the instruction
+// selector materialises).
+__device__ __forceinline__ int step_lane() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+typedef const __attribute__((address_space(4))) StepArgs* StepArgsConst;
+__device__ __forceinline__ const StepArgs& step_args() {
+  unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const StepArgs*)(StepArgsConst)p;
 }
 
-typedef void (*fused_kern_t)(KArgs, RArgs, int, const void*, int, const int*, const int*, const unsigned char*, unsigned int);
+template <int K>
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) void tc_env_kernel(StepArgs sa_unused) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const StepArgs& s0 = step_args();
+  const int env = s0.a.env0 + blockIdx.x;
+  if (env >= s0.a.N) return;
+  if (s0.mode == MODE_RESET && s0.mask && !s0.mask[env]) return;  // whole workgroup skips
+  live_in(s0.a, smem, env, s0.mode, s0.flags);
+  const int nsteps = s0.ma.nsteps;
+  for (int k = 0; k < nsteps; k++) {  // nsteps > 1 only without a raster launch behind this one (TC_F_NO_OBSERVATION)
+    const StepArgs& sa = step_args();  // re-read per step: see step_args()
+    const size_t esz = sa.cdtype == TC_F32 ? 4 : 8;
+    const size_t row0 = (size_t)k * sa.a.N;
+    sim_body<K>(sa.a, smem, env, sa.mode, (const char*)sa.car_control + row0 * 2 * esz, sa.cdtype, sa.maneuver + row0,
+                sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), step_lane());
+    __syncthreads();  // the next step reads the LiveLds record this one wrote
+  }
+  const StepArgs& s1 = step_args();
+  if (s1.mode != MODE_RENDER) live_out(s1.a, smem, env);
+}
+
+// Both stages in one launch: the same wavefront simulates its env and then rasterises it.  Saves one kernel
+// boundary (launch gap + one ramp-up / drain of the whole grid) per step.
+// tc_step_multi: the wavefront stays with its env for nsteps steps (envs are independent: no grid-wide synchronisation
+// between steps).  The map cache, kernel arguments and tables are fetched once per launch instead of once per step, the
+// env's state stays on chip (LDS) between steps, and the wavefronts of a SIMD drift apart, so that they no longer sit
+// in the same latency-bound phase at the same time and no step pays a grid ramp-up or waits for the slowest env.
+template <int K, bool THICK, int FMT>
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_kernel(StepArgs sa_unused) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const StepArgs& s0 = step_args();
+  const int env = s0.a.env0 + blockIdx.x;
+  if (env >= s0.a.N) return;
+  if (s0.mode == MODE_RESET && s0.mask && !s0.mask[env]) return;  // whole workgroup skips
+  live_in(s0.a, smem, env, s0.mode, s0.flags);
+  const int nsteps = s0.ma.nsteps;
+  for (int k = 0; k < nsteps; k++) {
+    const StepArgs& sa = step_args();  // re-read per step: see step_args()
+    const size_t esz = sa.cdtype == TC_F32 ? 4 : 8;
+    const size_t row0 = (size_t)k * sa.a.N;
+    const int tid = step_lane();
+    const bool draw = sim_body<K>(sa.a, smem, env, sa.mode, (const char*)sa.car_control + row0 * 2 * esz, sa.cdtype,
+                                  sa.maneuver + row0, sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), tid);
+    __syncthreads();  // draw list + count written by this wavefront are visible to it (vmcnt(0) + barrier)
+    if (draw) {
+      const StepArgs& sb = step_args();
+      const size_t obs_step = sb.ma.roll.obs ? (size_t)sb.a.N * ((size_t)sb.r.cam.H * sb.r.cam.W * (FMT == TC_FMT_CLASSES ? sb.r.C : 3)) : 0;
+      unsigned char* obs_base = sb.ma.roll.obs ? sb.ma.roll.obs : sb.r.obs;
+      raster_body<THICK, FMT>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid);
+    }
+  }
+  const StepArgs& s1 = step_args();
+  if (s1.mode != MODE_RENDER) live_out(s1.a, smem, env);
+}
+
+typedef void (*fused_kern_t)(StepArgs);
+// TC_DEV_FAST (make dev): only the K = 5 / thick / classes variants are instantiated -- a compile of seconds instead of
+// minutes for kernel work on cfg3.  Never shipped: the default build has no such macro.
 template <int K>
 static fused_kern_t pick_fused(bool thick, bool cls) {
+#ifdef TC_DEV_FAST
+  return tc_step_kernel<5, true, TC_FMT_CLASSES>;
+#else
   return thick ? (cls ? tc_step_kernel<K, true, TC_FMT_CLASSES> : tc_step_kernel<K, true, TC_FMT_RGB>)
                : (cls ? tc_step_kernel<K, false, TC_FMT_CLASSES> : tc_step_kernel<K, false, TC_FMT_RGB>);
+#endif
 }
 
 // =============================================================================================
@@ -1536,6 +1770,9 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   e->r_off_tab = R_OFF_TAB;
   e->r_off_bits = R_OFF_BITS;
   e->r_lds = e->r_off_bits + align_up(m.C * band_rows * dc.wpr * 4, 16);
+  // the env's parked state (tc_step_multi) sits behind whichever stage needs more, so that neither aliases it
+  L.off_live = align_up(L.total > e->r_lds ? L.total : e->r_lds, 16);
+  L.total = L.off_live + TC_LIVE_BYTES;
   if (L.total > 160 * 1024 || e->r_lds > 160 * 1024) {
     set_err("tc_env_create: map too large for one workgroup's LDS");
     delete e;
@@ -1552,6 +1789,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
         }
     }
   }
+#ifndef TC_DEV_FAST
   if (e->r_lds > 48 * 1024) {
     (void)hipFuncSetAttribute((const void*)tc_raster_kernel<true, TC_FMT_CLASSES>, hipFuncAttributeMaxDynamicSharedMemorySize, e->r_lds);
     (void)hipFuncSetAttribute((const void*)tc_raster_kernel<true, TC_FMT_RGB>, hipFuncAttributeMaxDynamicSharedMemorySize, e->r_lds);
@@ -1569,6 +1807,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
       return TC_E_HIP;
     }
   }
+#endif
   e->obs_bytes = (int64_t)dc.H * dc.W * (dc.format == TC_FMT_CLASSES ? m.C : 3);
   e->k.seg_cap = m.total_edges > 0 ? m.total_edges : 1;
   {
@@ -1764,7 +2003,7 @@ extern "C" int tc_env_set_noise(tc_env* e, int32_t n_blobs, int32_t max_radius, 
   return TC_OK;
 }
 
-static int launch_noise(tc_env* e, const int32_t* blobs, void* stream) {
+static int launch_noise(tc_env* e, const int32_t* blobs, void* stream, uint8_t* obs = nullptr) {
   NArgs n;
   memset(&n, 0, sizeof(n));
   const DevCam& c = e->k.cam;
@@ -1775,7 +2014,7 @@ static int launch_noise(tc_env* e, const int32_t* blobs, void* stream) {
   n.wpr = c.wpr;
   n.band_rows = c.band_rows;
   n.n_bands = c.n_bands;
-  n.obs = e->k.b.obs;
+  n.obs = obs ? obs : e->k.b.obs;
   n.blobs = blobs;
   n.n_blobs = e->noise_blobs;
   n.max_radius = e->noise_max_radius;
@@ -1880,7 +2119,7 @@ extern "C" int tc_env_set_camera(tc_env* e, const tc_camera_params* cam) {
 }
 
 static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
-                        int env0) {
+                        int env0, uint8_t* obs = nullptr) {
   RArgs r;
   memset(&r, 0, sizeof(r));
   r.N = e->k.N;
@@ -1911,7 +2150,7 @@ static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_c
   r.seg_g = seg_g;
   r.seg_n = seg_n;
   r.seg_cap = seg_cap;
-  r.obs = e->k.b.obs;
+  r.obs = obs ? obs : e->k.b.obs;
   r.mask = mask;
   r.off_tab = e->r_off_tab;
   r.off_bits = e->r_off_bits;
@@ -1920,25 +2159,34 @@ static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_c
 }
 
 static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
-                         void* stream, int env0 = 0, int count = -1) {
+                         void* stream, int env0 = 0, int count = -1, uint8_t* obs = nullptr) {
 #ifdef TC_TIMING
   if (g_tstamp && e->k.N > g_tstamp_n) {
     set_err("timing build: the installed stamp buffer is smaller than this env batch");
     return TC_E_INVALID;
   }
 #endif
-  RArgs r = make_rargs(e, seg_g, seg_n, seg_cap, mask, flags, env0);
+  RArgs r = make_rargs(e, seg_g, seg_n, seg_cap, mask, flags, env0, obs);
   if (count < 0) count = e->k.N;
+#ifdef TC_DEV_FAST
+  auto kern = tc_raster_kernel<true, TC_FMT_CLASSES>;
+#else
   const bool thick = r.cam.thickness > 1, cls = r.cam.format == TC_FMT_CLASSES;
   auto kern = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
                     : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
+#endif
   hipLaunchKernelGGL(kern, dim3(count), dim3(TC_NT), e->r_lds, (hipStream_t)stream, r);
   HIP_TRY(hipGetLastError());
   return TC_OK;
 }
 
+static bool fused_path(const tc_env* e, uint32_t flags) {
+  const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
+  return do_raster && e->fuse && e->kvar != 13;
+}
+
 static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t* man, const int32_t* spawn,
-                  const uint8_t* mask, uint32_t flags, void* stream) {
+                  const uint8_t* mask, uint32_t flags, void* stream, int nsteps = 1, const tc_rollout* roll = nullptr) {
   if (!e) return TC_E_INVALID;
   if (!e->bound) {
     set_err("tc_env_bind has not been called");
@@ -1961,11 +2209,19 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;
   const int slot = e->prof_n % TC_PROF_RING;
   const int kv = e->kvar;
+#ifdef TC_DEV_FAST
+  auto kern = tc_env_kernel<5>;
+#else
   auto kern = kv == 5 ? tc_env_kernel<5> : kv == 8 ? tc_env_kernel<8> : kv == 9 ? tc_env_kernel<9> : tc_env_kernel<13>;
-  const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
+#endif
+  const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && (e->k.b.obs || (roll && roll->obs));
   const int N = e->k.N;
+  MultiArgs ma;
+  memset(&ma, 0, sizeof(ma));
+  ma.nsteps = nsteps;
+  if (roll) ma.roll = *roll;
   // sub-batches only pay off with an observation to rasterise and enough envs per part; profiled steps stay whole
-  int parts = (do_raster && !prof && N >= 256 * e->split) ? e->split : 1;
+  int parts = (do_raster && !prof && N >= 256 * e->split && nsteps == 1) ? e->split : 1;
   hipStream_t main = (hipStream_t)stream;
   if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], main));
   if (parts > 1) HIP_TRY(hipEventRecord(e->fork_ev, main));
@@ -1976,15 +2232,27 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     KArgs k = e->k;
     k.env0 = 0;
     RArgs r = make_rargs(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, nullptr, flags, 0);
-    const int lds = e->k.lds.total > e->r_lds ? e->k.lds.total : e->r_lds;
-    hipLaunchKernelGGL(fk, dim3(N), dim3(TC_NT), lds, main, k, r, mode, cc, cdtype, man, spawn, mask, flags);
+    const int lds = e->k.lds.total;  // covers both stages and the parked state
+    StepArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.a = k;
+    sa.r = r;
+    sa.ma = ma;
+    sa.mode = mode;
+    sa.cdtype = cdtype;
+    sa.flags = flags;
+    sa.car_control = cc;
+    sa.maneuver = man;
+    sa.spawn_nodes = spawn;
+    sa.mask = mask;
+    hipLaunchKernelGGL(fk, dim3(N), dim3(TC_NT), lds, main, sa);
     HIP_TRY(hipGetLastError());
     if (prof) {  // one kernel: its whole duration is reported as the first interval, the second is empty
       HIP_TRY(hipEventRecord(e->ev[1][slot], main));
       HIP_TRY(hipEventRecord(e->ev[2][slot], main));
       e->prof_n++;
     }
-    if (e->noise_blobs > 0 && mode == MODE_STEP) return launch_noise(e, nullptr, stream);
+    if (e->noise_blobs > 0 && mode == MODE_STEP) return launch_noise(e, nullptr, stream, roll ? roll->obs : nullptr);
     return TC_OK;
   }
   for (int p = 0; p < parts; p++) {
@@ -1993,12 +2261,23 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     if (p > 0) HIP_TRY(hipStreamWaitEvent(st, e->fork_ev, 0));
     KArgs k = e->k;
     k.env0 = env0;
-    hipLaunchKernelGGL(kern, dim3(env1 - env0), dim3(TC_NT), k.lds.total, st, k, mode, cc, cdtype, man, spawn, mask, flags);
+    StepArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.a = k;
+    sa.ma = ma;
+    sa.mode = mode;
+    sa.cdtype = cdtype;
+    sa.flags = flags;
+    sa.car_control = cc;
+    sa.maneuver = man;
+    sa.spawn_nodes = spawn;
+    sa.mask = mask;
+    hipLaunchKernelGGL(kern, dim3(env1 - env0), dim3(TC_NT), k.lds.total, st, sa);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
     if (do_raster) {
       int rc = launch_raster(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, mode == MODE_RESET ? mask : nullptr, flags, st, env0,
-                             env1 - env0);
+                             env1 - env0, roll ? roll->obs : nullptr);
       if (rc != TC_OK) return rc;
     }
     if (p > 0) HIP_TRY(hipEventRecord(e->join_ev[p], st));
@@ -2008,7 +2287,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     HIP_TRY(hipEventRecord(e->ev[2][slot], main));
     e->prof_n++;
   }
-  if (do_raster && e->noise_blobs > 0 && mode == MODE_STEP) return launch_noise(e, nullptr, stream);
+  if (do_raster && e->noise_blobs > 0 && mode == MODE_STEP) return launch_noise(e, nullptr, stream, roll ? roll->obs : nullptr);
   return TC_OK;
 }
 
@@ -2021,6 +2300,47 @@ extern "C" int tc_step(tc_env* e, const void* car_control, int32_t control_dtype
                        uint32_t flags, void* stream) {
   if (!car_control || !maneuver || (control_dtype != TC_F32 && control_dtype != TC_F64)) return TC_E_INVALID;
   return launch(e, MODE_STEP, car_control, control_dtype, maneuver, nullptr, nullptr, flags, stream);
+}
+
+extern "C" int tc_step_multi(tc_env* e, const void* car_control, int32_t control_dtype, const int32_t* maneuver,
+                             int32_t n_steps, uint32_t flags, const tc_rollout* rollout, void* stream) {
+  if (!e || !car_control || !maneuver || (control_dtype != TC_F32 && control_dtype != TC_F64) || n_steps < 1) return TC_E_INVALID;
+  if (!e->bound) {
+    set_err("tc_env_bind has not been called");
+    return TC_E_UNBOUND;
+  }
+  const bool want_obs = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && (e->k.b.obs || (rollout && rollout->obs));
+  // one launch for all steps: the fused kernel, or the simulate kernel alone when nothing is rendered
+  const bool one_launch = want_obs ? (e->fuse && e->kvar != 13 && e->noise_blobs == 0) : true;
+  if (one_launch) return launch(e, MODE_STEP, car_control, control_dtype, maneuver, nullptr, nullptr, flags, stream, n_steps, rollout);
+  // two-launch maps (and the stand-alone noise pass): one step per pair of launches, rollout rows advanced on the host
+  const size_t N = (size_t)e->k.N, esz = control_dtype == TC_F32 ? 4 : 8;
+  for (int k = 0; k < n_steps; k++) {
+    tc_rollout r;
+    memset(&r, 0, sizeof(r));
+    if (rollout) {
+      r.obs = rollout->obs ? rollout->obs + (size_t)k * N * (size_t)e->obs_bytes : nullptr;
+      r.reward = rollout->reward ? rollout->reward + k * N : nullptr;
+      r.terminated = rollout->terminated ? rollout->terminated + k * N : nullptr;
+      r.truncated = rollout->truncated ? rollout->truncated + k * N : nullptr;
+      r.cte = rollout->cte ? rollout->cte + k * N : nullptr;
+      r.heading_error = rollout->heading_error ? rollout->heading_error + k * N : nullptr;
+    }
+    int rc = launch(e, MODE_STEP, (const char*)car_control + (size_t)k * N * 2 * esz, control_dtype, maneuver + k * N, nullptr,
+                    nullptr, flags, stream, 1, rollout ? &r : nullptr);
+    if (rc != TC_OK) return rc;
+  }
+  return TC_OK;
+}
+
+extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t* fused, int32_t* kvar, char* name, int32_t name_cap) {
+  if (!e) return TC_E_INVALID;
+  const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
+  const bool f = fused_path(e, flags) && e->split == 1;
+  if (fused) *fused = f ? 1 : 0;
+  if (kvar) *kvar = e->kvar;
+  if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", f ? "tc_step_kernel" : do_raster ? "tc_env_kernel+tc_raster_kernel" : "tc_env_kernel");
+  return TC_OK;
 }
 
 extern "C" int tc_render_segments(tc_env* e, const int32_t* segments, const int32_t* counts, int32_t capacity,

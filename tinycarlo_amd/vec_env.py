@@ -364,6 +364,66 @@ class TinyCarloVecEnv(gym.Env):
                                         self._stream()), "tc_step")
         self._keep = (car_control, maneuver)
 
+    ROLLOUT_KEYS = ("obs", "reward", "terminated", "truncated", "cte", "heading_error")
+
+    def alloc_rollout(self, n_steps: int, keys: Sequence[str] = ("obs", "reward", "terminated", "truncated")) -> Dict[str, torch.Tensor]:
+        """Device tensors for the per-step outputs of `step_multi`: [n_steps, num_envs, ...] each."""
+        K, N, dev = int(n_steps), self.num_envs, self.device
+        shapes = {"obs": ((K, N) + self._obs_shape, torch.uint8), "reward": ((K, N), torch.float64),
+                  "terminated": ((K, N), torch.uint8), "truncated": ((K, N), torch.uint8),
+                  "cte": ((K, N), torch.float64), "heading_error": ((K, N), torch.float64)}
+        for k in keys:
+            if k not in shapes:
+                raise ValueError(f"unknown rollout key {k!r}; choose from {self.ROLLOUT_KEYS}")
+        return {k: torch.zeros(shapes[k][0], dtype=shapes[k][1], device=dev) for k in keys}
+
+    def step_multi(self, car_control: torch.Tensor, maneuver: torch.Tensor,
+                   rollout: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        """K steps in ONE launch (tc_step_multi): the caller's `for k: env.step(action[k])` loop of
+        env.py:115-147 with the actions known in advance.  car_control [K, N, 2] float32|float64, maneuver [K, N]
+        int32, both on the device.  Bit-identical to K calls of `step_device`; self.state / self.out hold step K-1
+        afterwards.  `rollout` (from `alloc_rollout`) receives every step's outputs; with rollout["obs"] the
+        observations go there and self.out["obs"] is left untouched."""
+        if not self._was_reset:
+            raise RuntimeError("step_multi() before reset()")
+        if car_control.dim() != 3 or tuple(car_control.shape[1:]) != (self.num_envs, 2):
+            raise ValueError(f"car_control must be [K, {self.num_envs}, 2], got {tuple(car_control.shape)}")
+        K = int(car_control.shape[0])
+        if K < 1 or tuple(maneuver.shape) != (K, self.num_envs):
+            raise ValueError(f"maneuver must be [{K}, {self.num_envs}], got {tuple(maneuver.shape)}")
+        if car_control.device != self.device or maneuver.device != self.device:
+            raise ValueError("step_multi takes device tensors")
+        if car_control.dtype not in (torch.float32, torch.float64) or maneuver.dtype != torch.int32:
+            raise ValueError("car_control must be float32|float64 and maneuver int32")
+        if not (car_control.is_contiguous() and maneuver.is_contiguous()):
+            raise ValueError("step_multi takes contiguous tensors")
+        self._note_fresh()
+        r = nat.Rollout()
+        if rollout:
+            want = {"obs": (torch.uint8, (K, self.num_envs) + self._obs_shape)}
+            for k in ("reward", "cte", "heading_error"):
+                want[k] = (torch.float64, (K, self.num_envs))
+            for k in ("terminated", "truncated"):
+                want[k] = (torch.uint8, (K, self.num_envs))
+            for k, t in rollout.items():
+                if k not in want:
+                    raise ValueError(f"unknown rollout key {k!r}")
+                dt_, shp = want[k]
+                if t.dtype != dt_ or tuple(t.shape) != shp or t.device != self.device or not t.is_contiguous():
+                    raise ValueError(f"rollout[{k!r}] must be a contiguous {dt_} tensor of shape {shp} on {self.device}")
+                setattr(r, k, t.data_ptr())
+        dt = nat.F64 if car_control.dtype == torch.float64 else nat.F32
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_step_multi(self._h, car_control.data_ptr(), dt, maneuver.data_ptr(), K, self._flags(),
+                                              C.byref(r) if rollout else None, self._stream()), "tc_step_multi")
+        self._keep = (car_control, maneuver, rollout)
+
+    def launch_info(self) -> Dict[str, Any]:
+        """What a step with the current settings launches (tc_env_launch_info): for benchmark labels."""
+        f, kv, name = C.c_int32(), C.c_int32(), C.create_string_buffer(64)
+        nat.check(nat.lib().tc_env_launch_info(self._h, self._flags(), C.byref(f), C.byref(kv), name, 64), "tc_env_launch_info")
+        return {"fused": bool(f.value), "kvar": kv.value, "kernel": name.value.decode()}
+
     def request_reset(self, mask: torch.Tensor) -> None:
         """Marks envs for re-spawning at the start of the next autoreset step, in addition to the ones the engine
         flagged itself (terminated | truncated).  Torch-side termination wrappers call this with their result;
@@ -377,11 +437,13 @@ class TinyCarloVecEnv(gym.Env):
 
     def profile(self, every: int = 1) -> None:
         """Record HIP events around the two kernels of every `every`-th step (ring of the last 64 samples); 0 = off."""
-        nat.check(nat.lib().tc_env_profile(self._h, int(every)), "tc_env_profile")
+        with torch.cuda.device(self.device):  # the events must belong to the device whose stream records them
+            nat.check(nat.lib().tc_env_profile(self._h, int(every)), "tc_env_profile")
 
     def profile_read(self) -> Dict[str, float]:
         a, b, n = C.c_double(), C.c_double(), C.c_int32()
-        nat.check(nat.lib().tc_env_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "tc_env_profile_read")
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_env_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "tc_env_profile_read")
         return {"simulate_us": a.value, "raster_us": b.value, "launches": n.value}
 
     def render_current(self) -> None:
