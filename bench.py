@@ -203,6 +203,8 @@ def main():
     env.reset(seed=shard_seed(0, rank, n))  # env i of rank r is the reference env seeded r*n + i
     K, W = args.steps, args.warmup
     period = min(max(K + W, 64), 1024)  # distinct action batches kept in HBM (reused cyclically beyond that)
+    if M >= 1:
+        period = max(M, period // M * M)  # a multiple of the launch size: launches do not straddle the wrap-around
     cc, man = gen_actions(n, period, seed=rank, device=device)
     roll = None
     if M >= 1 and not w["no_obs"]:
@@ -219,17 +221,23 @@ def main():
                 i = t % period
                 env.step_device(cc[i], man[i])
             return cnt
+        # cnt steps as ceil(cnt / m) launches of (almost) equal size: no short last launch skews the per-launch means
+        n_launch = -(-cnt // m)
+        base, rem = divmod(cnt, n_launch)
         t = t0
-        while t < t0 + cnt:
-            i = t % period
-            kk = min(m, t0 + cnt - t, period - i)
-            if sink is not None:
-                sink.launch(cc[i:i + kk], man[i:i + kk])
-            else:
-                r = roll if kk == M else {k_: v[:kk] for k_, v in roll.items()}
-                env.step_multi(cc[i:i + kk], man[i:i + kk], rollout=r)
-            t += kk
-            nl += 1
+        for j in range(n_launch):
+            want = base + (1 if j < rem else 0)
+            while want > 0:  # (a launch is only split where the cyclic action buffer wraps around)
+                i = t % period
+                kk = min(want, period - i)
+                if sink is not None:
+                    sink.launch(cc[i:i + kk], man[i:i + kk])
+                else:
+                    r = roll if kk == M else {k_: v[:kk] for k_, v in roll.items()}
+                    env.step_multi(cc[i:i + kk], man[i:i + kk], rollout=r)
+                t += kk
+                want -= kk
+                nl += 1
         return nl
 
     def timed(t0, cnt, sink=None, m=None):
@@ -309,16 +317,27 @@ def main():
     b_obs = 0 if w["no_obs"] else (C * H * Wd if w["fmt"] == "classes" else 3 * H * Wd)
     bytes_per_env_step = B_STATE + b_obs
     step_s = ev_ms / 1e3 / K  # HIP events on the launch stream around the K timed steps
-    info = env.launch_info()  # what the library really launches (not guessed from timings)
+    info = env.launch_info(max(M, 1))  # what the library really launches (not guessed from timings)
     kname = info["kernel"]
     fused = info["fused"]
     spl = M if M >= 1 else 1                       # steps per launch of the dominant kernel
     full_launches = (K // M) if M >= 1 else K      # the sampled means below include a short last launch if K % M != 0
-    kernel_s = (prof["simulate_us"] + (prof["raster_us"] if b_obs and not fused else 0.0)) * 1e-6  # per LAUNCH
     steps_in_sampled = K / max(n_l, 1)             # mean steps per launch over the timed region
-    kbytes = bytes_per_env_step * n * steps_in_sampled
+    two = "+" in kname                             # simulate launch + frame (or raster) launch
+    if two:
+        # The dominant kernel is the one that writes the observations (tc_frame_kernel: camera + raster of one frame per
+        # workgroup).  Its algorithmic bytes per frame: the observation, written once, plus the 32-byte pose row it
+        # reads; the 240 B of state / action / info traffic belong to the simulate launch in front of it.
+        dom = kname.split("+")[-1]
+        kernel_s = prof["raster_us"] * 1e-6        # per LAUNCH (HIP events around that kernel on the launch stream)
+        dom_bytes_per_frame = b_obs + 32
+    else:
+        dom = kname
+        kernel_s = prof["simulate_us"] * 1e-6
+        dom_bytes_per_frame = bytes_per_env_step
+    kbytes = dom_bytes_per_frame * n * steps_in_sampled
     achieved = kbytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(args.workload, kname, spl) if n == WORKLOADS[args.workload]["envs"] else (None, None)
+    traffic, traffic_src = pmc_traffic(args.workload, dom, spl) if n == WORKLOADS[args.workload]["envs"] else (None, None)
     out = {
         "metric": "env-steps/sec (whole node)",
         "value": world * n * K / dt,
@@ -346,13 +365,17 @@ def main():
                    "lds_bytes_per_env": env.lds_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": kname, "kernel_us": kernel_s * 1e6, "steps_per_launch": steps_in_sampled,
+                     "kernel": dom, "kernel_us": kernel_s * 1e6, "steps_per_launch": steps_in_sampled,
                      "kernel_us_per_step": kernel_s * 1e6 / steps_in_sampled if steps_in_sampled else None,
-                     "algorithmic_bytes_per_launch": kbytes, "algorithmic_bytes_per_env_step": bytes_per_env_step,
-                     "kernels_us": ({kname: prof["simulate_us"]} if (fused or not b_obs) else
-                                    {"tc_env_kernel": prof["simulate_us"], "tc_raster_kernel": prof["raster_us"]}),
+                     "algorithmic_bytes_per_launch": kbytes, "algorithmic_bytes_per_unit": dom_bytes_per_frame,
+                     "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                     "launches_per_call": kname,
+                     "kernels_us": ({kname: prof["simulate_us"]} if not two else
+                                    {kname.split("+")[0]: prof["simulate_us"], dom: prof["raster_us"]}),
                      "event_samples": prof["launches"], "full_launches": full_launches,
-                     "step_us": step_s * 1e6, "step_achieved_GBs": bytes_per_env_step * n / step_s / 1e9},
+                     # the whole step (all launches, gaps included) against SURVEY 8d's bytes per env-step
+                     "step_us": step_s * 1e6, "step_achieved_GBs": bytes_per_env_step * n / step_s / 1e9,
+                     "step_frac": bytes_per_env_step * n / step_s / 1e9 / HBM_PEAK_GBS},
     }
     if gathered is not None:
         out["gathered"] = gathered

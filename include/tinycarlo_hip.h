@@ -239,8 +239,10 @@ int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const i
  *   rollout (may be NULL): per-step copies of the outputs a learner reads, each [K][N] (obs: [K][N][obs_bytes]) or
  *   NULL.  With rollout->obs the observation of step k goes to rollout->obs[k] and the bound obs buffer is left
  *   untouched; without it every step stores its observation into the bound buffer (which ends up holding the last).
- * Maps that need the two-launch path (a lane-line layer with more than 576 nodes or edges, or TC_FUSE=0) are served
- * by K pairs of launches from the host -- same results, no amortisation. */
+ * Launches: ONE simulate launch that loops over the K steps (one wavefront per env) and, when observations are
+ * rendered, ONE raster launch of K x N workgroups over the frames (without rollout->obs only the last step's frame is
+ * drawn: the others would be overwritten); env var TC_MULTI_SPLIT=0 selects a single fused launch instead, in which the
+ * same wavefront also rasterises each of its env's frames. */
 typedef struct {
   uint8_t* obs;          /* [K][N][tc_env_obs_bytes] */
   double* reward;        /* [K][N] */
@@ -252,11 +254,12 @@ typedef struct {
 int tc_step_multi(tc_env* env, const void* car_control, int32_t control_dtype, const int32_t* maneuver, int32_t n_steps,
                   uint32_t flags, const tc_rollout* rollout, void* stream);
 
-/* What the library launches for a step with the current settings (for benchmark labels, not for control flow):
- * fused = 1 when simulate + raster run as one kernel; kvar = register-cache variant of the simulate stage
- * (5, 8, 9, 13); name receives the kernel symbol prefix ("tc_step_kernel", "tc_env_kernel+tc_raster_kernel" or
- * "tc_env_kernel"), at most name_cap bytes including the terminator. */
-int tc_env_launch_info(const tc_env* env, uint32_t flags, int32_t* fused, int32_t* kvar, char* name, int32_t name_cap);
+/* What the library launches for a call of n_steps steps (1 = tc_step) with the current settings -- for benchmark
+ * labels, not for control flow: fused = 1 when simulate + raster run as one kernel; kvar = register-cache variant of
+ * the simulate stage (5, 8, 9, 13); name receives the kernel symbol prefix ("tc_step_kernel",
+ * "tc_env_kernel+tc_raster_kernel" or "tc_env_kernel"), at most name_cap bytes including the terminator. */
+int tc_env_launch_info(const tc_env* env, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar, char* name,
+                       int32_t name_cap);
 
 /* Renderer.render_camera_frame_{rgb,classes} alone (renderer.py:36-51): rasterise caller-provided segment lists
  * into the bound observation tensor.  segments: device int32 [N][capacity][5] rows of (layer, x0, y0, x1, y1) --

@@ -126,8 +126,8 @@ def lib():
     L.tc_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.tc_step_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint32,
                                 C.POINTER(Rollout), C.c_void_p]
-    L.tc_env_launch_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p,
-                                     C.c_int32]
+    L.tc_env_launch_info.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                     C.c_char_p, C.c_int32]
     L.tc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.tc_render_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     if L.tc_abi_version() != ABI_VERSION:

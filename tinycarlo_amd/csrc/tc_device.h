@@ -121,6 +121,32 @@ __device__ inline void wave_argmin(double& v, int& idx) {
   idx = __shfl(idx, 0);
 }
 
+// The same for TC_AG layers at once: the TC_AG reductions are independent, so their shuffles are issued together and each
+// of the 6 stages waits for the LDS crossbar once instead of once per layer (one reduction after the other was 5 x ~2 k
+// clocks of a wavefront's step on simple_layout, almost all of it latency).  bd / best are indexed by unrolled constants
+// only and stay in registers.
+#define TC_AG 5
+__device__ __forceinline__ void wave_argmin_group(double (&bd)[TC_AG], int (&best)[TC_AG]) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double ov[TC_AG];
+    int oi[TC_AG];
+#pragma unroll
+    for (int g = 0; g < TC_AG; g++) {
+      ov[g] = __shfl_down(bd[g], off);
+      oi[g] = __shfl_down(best[g], off);
+    }
+#pragma unroll
+    for (int g = 0; g < TC_AG; g++) {
+      const bool take = (oi[g] >= 0) && (best[g] < 0 || ov[g] < bd[g] || (ov[g] == bd[g] && oi[g] < best[g]));
+      bd[g] = take ? ov[g] : bd[g];
+      best[g] = take ? oi[g] : best[g];
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < TC_AG; g++) best[g] = __builtin_amdgcn_readfirstlane(best[g]);  // lane 0 holds the result
+}
+
 // ------------------------------------------------------------------ layer.py
 // layer.py:144-164
 __device__ inline double d_distance_to_edge(double n1x, double n1y, double n2x, double n2y, double px, double py) {
@@ -141,6 +167,29 @@ __device__ inline bool d_within_bounds(double n0x, double n0y, double n1x, doubl
   double a0 = tc_fabs(d_clip_angle(tc_atan2(py - n0y, px - n0x) - ori_fwd));
   double a1 = tc_fabs(d_clip_angle(tc_atan2(py - n1y, px - n1x) - ori_rev));
   return a0 <= TC_PI / 2 && a1 <= TC_PI / 2;
+}
+
+// The same decision without the two atan2 whenever it is not close: |angle(p - n, +-edge)| <= pi/2 is the sign of a dot
+// product.  The reference's a0 / a1 carry at most a few 1e-16 of rounding (two atan2 of <= 1-2 ulp, one subtraction,
+// clip_angle's +-2 pi), so its comparison with pi/2 can only disagree with exact arithmetic when the true angle is
+// within ~1e-14 of pi/2; here the dot product decides only when |cos| of that angle exceeds 1e-6 (i.e. the angle is
+// at least 1e-6 rad away from pi/2), which also dwarfs the dot product's own rounding error (~1e-16 relative to
+// |v||e|).  Everything else -- angles within 1e-6 of pi/2, zero-length edges, NaNs -- reports `certain = false` and
+// the caller evaluates d_within_bounds itself.  v = p - n and e = n1 - n0 are the very (rounded) vectors the reference
+// hands to atan2 (layer.py:140-141), so both routes judge the same angle.
+__device__ inline bool d_within_bounds_filter(double n0x, double n0y, double n1x, double n1y, double px, double py,
+                                              bool& certain) {
+  certain = true;
+  if (px == n0x && py == n0y) return true;
+  if (px == n1x && py == n1y) return true;
+  const double ex = n1x - n0x, ey = n1y - n0y;
+  const double ax = px - n0x, ay = py - n0y, bx = px - n1x, by = py - n1y;
+  const double dot0 = ax * ex + ay * ey;     // angle between (p - n0) and the edge direction
+  const double dot1 = -(bx * ex + by * ey);  // angle between (p - n1) and the reversed edge
+  const double ee = ex * ex + ey * ey;
+  const double lim0 = 1e-12 * ((ax * ax + ay * ay) * ee), lim1 = 1e-12 * ((bx * bx + by * by) * ee);
+  certain = (dot0 * dot0 > lim0) && (dot1 * dot1 > lim1);  // false for NaNs and zero-length vectors
+  return dot0 > 0 && dot1 > 0;
 }
 
 // layer.py:179-181 for a lanepath edge (a,b): table entry of the first a->b edge
@@ -362,8 +411,7 @@ __device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuv
 // car.py:70-125; returns truncated
 // have_trig: s.cth / s.sth already hold cos / sin of s.theta (left there by the front-axle update of the previous step
 // of the same launch): the same function of the same argument, so reusing them changes no bit
-__device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, double v_in, double s_in, int maneuver,
-                                 int& status, PathInfo& pi, bool have_trig, const int tid) {
+__device__ inline void d_car_kinematics(const DevCar& c, CarState& s, double v_in, double s_in, bool have_trig) {
   double dt = c.T;
   double nv = v_in * c.max_velocity;
   if (c.has_max_acceleration)
@@ -396,7 +444,9 @@ __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, 
     double nx = vyn, ny = -vxn;
     double tx = nx * s.radius, ty = ny * s.radius;
     double cd = tc_cos(dyaw), sd = tc_sin(dyaw);
-    double r0 = __builtin_fma(cd, tx, (-sd) * ty);  // numpy's dgemv association, see oracle/tc_oracle.c
+    // R_M.dot([tx, ty]) (car.py:111-113) is numpy's dgemv: row i = fma(R[i][0], tx, R[i][1] * ty) on x86-64 with FMA
+    // (tools/numpy_matmul_probe.py: 5 000 of 5 000 random cases; the unfused form matches 67 %)
+    double r0 = __builtin_fma(cd, tx, (-sd) * ty);
     double r1 = __builtin_fma(sd, tx, cd * ty);
     s.x = s.x - tx + r0;
     s.y = s.y - ty + r1;
@@ -407,12 +457,20 @@ __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, 
       s.theta += 2 * TC_PI;
     d_update_front(c, s);
   }
+}
+
+// car.py:70-125 = kinematics (above), then lanepath tracking; returns truncated
+__device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, double v_in, double s_in, int maneuver,
+                                 int& status, PathInfo& pi, bool have_trig, const int tid) {
+  d_car_kinematics(c, s, v_in, s_in, have_trig);
   return d_find_local_path(m, s, maneuver, status, pi, tid);  // ONE call site: the function is ~2 k instructions inlined
 }
 
 // ------------------------------------------------------------------ camera.py helpers
 // C[i][j] = one chain of fused multiply-adds over ascending t from a zero accumulator: the association of numpy's
-// `A @ B` (OpenBLAS dgemm on x86-64 with FMA) that the reference's camera runs on -- see matmul() in oracle/tc_oracle.c.
+// `A @ B` (OpenBLAS dgemm on x86-64 with FMA) that the reference's camera runs on (camera.py:62,131,138; isolated with
+// exact rational arithmetic by tools/numpy_matmul_probe.py: R@T, E@car3d, pose@points and K@P reproduce bit for bit
+// with this form and with no other tried).
 // The fma here is an explicit operation of the algorithm, not a contraction (the library is built -ffp-contract=off).
 template <int N, int K, int P>
 __device__ inline void d_matmul(const double* A, const double* B, double* C) {

@@ -34,9 +34,19 @@ __device__ long long* tc_tstamp = nullptr;  // [N][32]
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                            \
     if (_tp && threadIdx.x == 0) _tp[(size_t)env * 32 + (i)] = clock64();                  \
   } while (0)
+// the constant 100 MHz counter next to the shader clock: (stamp 13 - stamp 0) / (stamp 31 - stamp 30) x 100 MHz is the
+// clock the chip actually holds while the kernel runs
+#define TSTAMP_REAL(i)                                                                     \
+  do {                                                                                     \
+    long long* _tp = tc_tstamp;                                                            \
+    if (_tp && threadIdx.x == 0) _tp[(size_t)env * 32 + (i)] = wall_clock64();            \
+  } while (0)
 #else
 #define TSTAMP(i) \
   do {            \
+  } while (0)
+#define TSTAMP_REAL(i) \
+  do {                 \
   } while (0)
 #endif
 
@@ -238,11 +248,66 @@ __device__ inline void cache_edges(MapCache<K>& c, const DevMap& m, int base, in
 // index by the lane that owns the chain's first edge.  List entries carry (edge, target | other << 16)
 // so the chain loops touch LDS only.
 // Works on one camera group: edges ge0 .. ge0+ne-1 (ids below are relative to ge0), node ids relative to gn0.
+// camera.py:112-122 __point_on_line_at_z(p0 = P[o], p1 = P[t], tz), stored into P[t]
+__device__ __forceinline__ void cam_move_to_plane(double* Px, double* Py, double* Pz, int o, int t, double tz) {
+  double d0 = Px[o] - Px[t], d1 = Py[o] - Py[t], d2 = Pz[o] - Pz[t];
+  if (d2 == 0) {
+    double qn = __longlong_as_double(0x7ff8000000000000LL);
+    Px[t] = qn;
+    Py[t] = qn;
+    Pz[t] = qn;
+  } else {
+    double tt = (tz - Pz[t]) / d2;
+    double aa = Px[t] + tt * d0, bb = Py[t] + tt * d1, cc = Pz[t] + tt * d2;
+    Px[t] = aa;
+    Py[t] = bb;
+    Pz[t] = cc;
+  }
+}
+
 template <int K>
 __device__ inline void cam_fixup_pass(MapCache<K>& mc, const DevMap& m, bool reload, int ge0, int ne, int gn0, int nwin,
                                       double* Px, double* Py, double* Pz, unsigned char* flg, int bit, bool target_e0,
                                       double tz, int* list, int* cnt, int tid) {
   // *cnt was zeroed (and a barrier passed) before the call
+  if (!reload) {
+    // The group's edges sit in this wavefront's registers (one window).  Typical frame: a handful of edges straddle
+    // the plane, each with a target node of its own.  Then no list is needed at all: the lane holding a straddling
+    // edge moves that edge's target itself.  Only when two straddling edges share a target does the order of
+    // camera.py's loop matter -- detected by every selecting lane writing its edge id into claim[target] and reading
+    // it back (one wavefront: LDS operations complete in program order) -- and then the exact list replay below runs.
+    int sel = 0;  // bit k: slot k of this lane straddles the plane in the direction of this pass
+    int* claim = list;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int e = k * TC_NT + tid;
+      if (e < ne) {
+        const int2 ed = mc.ed[k];
+        const bool fa = flg[ed.x] & bit, fb = flg[ed.y] & bit;
+        if (target_e0 ? (!fa && fb) : (fa && !fb)) {
+          sel |= 1 << k;
+          claim[target_e0 ? ed.x : ed.y] = e;
+        }
+      }
+    }
+    if (__ballot(sel != 0) == 0) return;  // nothing straddles: flags, nodes, list and counter untouched
+    bool dup = false;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+      if ((sel >> k) & 1) dup |= claim[target_e0 ? mc.ed[k].x : mc.ed[k].y] != k * TC_NT + tid;
+    if (__ballot(dup) == 0) {
+#pragma unroll
+      for (int k = 0; k < K; k++)
+        if ((sel >> k) & 1) {
+          const int t = target_e0 ? mc.ed[k].x : mc.ed[k].y, o = target_e0 ? mc.ed[k].y : mc.ed[k].x;
+          cam_move_to_plane(Px, Py, Pz, o, t, tz);
+          flg[t] |= (unsigned char)bit;  // targets are distinct: no two lanes touch the same byte
+        }
+      __syncthreads();
+      return;
+    }
+    __syncthreads();  // claim[] aliases the list the exact path is about to build
+  }
   for (int w = 0; w < nwin; w++) {
     if (reload) cache_edges(mc, m, ge0 + w * K * TC_NT, ge0 + ne, gn0, tid);
 #pragma unroll
@@ -271,20 +336,7 @@ __device__ inline void cam_fixup_pass(MapCache<K>& mc, const DevMap& m, bool rel
     if (!first) continue;
     int cur = e, o = (unsigned)list[2 * k + 1] >> 16;  // the end that stays
     for (int guard = 0; guard < n; guard++) {
-      // camera.py:112-122 __point_on_line_at_z(p0 = P[o], p1 = P[t], tz)
-      double d0 = Px[o] - Px[t], d1 = Py[o] - Py[t], d2 = Pz[o] - Pz[t];
-      if (d2 == 0) {
-        double qn = __longlong_as_double(0x7ff8000000000000LL);
-        Px[t] = qn;
-        Py[t] = qn;
-        Pz[t] = qn;
-      } else {
-        double tt = (tz - Pz[t]) / d2;
-        double aa = Px[t] + tt * d0, bb = Py[t] + tt * d1, cc = Pz[t] + tt * d2;
-        Px[t] = aa;
-        Py[t] = bb;
-        Pz[t] = cc;
-      }
+      cam_move_to_plane(Px, Py, Pz, o, t, tz);
       int nxt = 0x7fffffff, no = 0;
       for (int j = 0; j < n; j++) {
         const int ej = list[2 * j], pj = list[2 * j + 1];
@@ -437,30 +489,25 @@ __device__ __forceinline__ void live_out(const KArgs& a, unsigned char* smem, in
 // (~1 KB) would be copied to scratch by every lane (the inliner's cost threshold is close: measured 47.9 k vs 47.6 k)
 // One step of one env: reads and rewrites the env's LiveLds record; the caller's buffers are only touched by live_in /
 // live_out (and the per-step rollout rows of `roll`).
+// what the camera needs of an env's state: rear-axle position and cos / sin of MINUS the heading (car.py:159-165)
+struct FramePose {
+  double x, y, cth, sth;
+};
+
 template <int K>
-__device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, int env, int mode,
+__device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, int env, int mode,
                                 const void* car_control, int cdtype,
                                 const int* maneuver, const int* spawn_nodes, const unsigned char* mask,
-                                unsigned int flags, const RollStep& roll, const int tid) {
+                                unsigned int flags, const RollStep& roll, const int tid, MapCache<K>& mc, FramePose& fp) {
 
   TSTAMP(0);
+  TSTAMP_REAL(30);
   const DevMap& m = a.m;
   const tc_buffers& b = a.b;
   // map windows of 64*K nodes / edges; one window (the usual case) is fetched now and kept in registers
   const int nwin_n = (m.total_nodes + TC_NT * K - 1) / (TC_NT * K), nwin_e = (m.total_edges + TC_NT * K - 1) / (TC_NT * K);
   const bool single = a.n_grp == 1 && nwin_n <= 1 && nwin_e <= 1;
-  MapCache<K> mc;
-  if (single) {
-    cache_nodes(mc, m, 0, m.total_nodes, tid);
-    cache_edges(mc, m, 0, m.total_edges, 0, tid);
-  }
-  double* Px = (double*)(smem + a.lds.off_p);
-  double* Py = Px + a.cap_nodes;
-  double* Pz = Py + a.cap_nodes;
-  double* dn = Px;  // phase B alias
-  unsigned char* flg = smem + a.lds.off_flg;
-  int* list = (int*)(smem + a.lds.off_list);
-  int* cnt = (int*)(smem + a.lds.off_cnt);
+  double* dn = (double*)(smem + a.lds.off_p);  // phase B: one double per lane-line node (aliases the camera's node buffer)
 
   // ---- state: all lanes read the same LDS words (broadcast)
   LiveLds* lv = (LiveLds*)(smem + a.lds.off_live);
@@ -523,7 +570,10 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
       }
       v = d_np_clip(v, -1.0, 1.0);  // env.py:118
       st = d_np_clip(st, -1.0, 1.0);
-      trunc = d_car_step(m, a.car, s, v, st, maneuver[env], status, pinfo, have_trig, tid);
+      const int man = maneuver[env];
+      d_car_kinematics(a.car, s, v, st, have_trig);
+      TSTAMP(23);
+      trunc = d_find_local_path(m, s, man, status, pinfo, tid);
       have_trig = true;
     }
   }
@@ -591,6 +641,13 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     }
 
     TSTAMP(2);
+    // The map window is fetched here, behind phase A, and not at the top of the step: across the scalar phase its 30
+    // registers per lane were what pushed the fused kernel over 128 VGPRs (the allocator answered by spilling the node
+    // half to scratch and reloading it here).  The lines are L1 / L2 resident after the first step of a launch.
+    if (single) {  // (the camera stage behind this one finds the window loaded)
+      cache_nodes(mc, m, 0, m.total_nodes, tid);
+      cache_edges(mc, m, 0, m.total_edges, 0, tid);
+    }
     // ---- phase B: lane-line distances (car.py:55-64)
     const int C = m.C;
     double dist_l = 0;  // lane l < C: distance to lane-line layer l (0 while the info is empty, car.py:47-51)
@@ -606,34 +663,42 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
       __syncthreads();
       TSTAMP(14);
       int my_e = -1;
-      int cur_w = single ? 0 : -1;  // the edge window mc.ed holds.  A layer's edges are contiguous, so it overlaps one or
-                                    // two windows; reloading every window for every layer was 10 global loads per step
-                                    // on knuffingen (2 windows x 5 layers) where 2 are needed
-      for (int l = 0; l < C; l++) {
-        const int eo = m.edge_off[l], eend = m.edge_off[l + 1];
-        int best = -1;
-        double bd = 0;
+      // layer.py:43 for every layer: each lane scans its edges once (ascending index) and keeps one partial per layer
+      // of the current group of TC_AG layers; the group's reductions then run together (wave_argmin_group).  A layer's
+      // edges are contiguous, so edge e belongs to group layer g iff edge_off[l0 + g] <= e < edge_off[l0 + g + 1].
+      for (int l0 = 0; l0 < C; l0 += TC_AG) {
+        double bd[TC_AG];
+        int best[TC_AG], lo[TC_AG], hi[TC_AG];
+#pragma unroll
+        for (int g = 0; g < TC_AG; g++) {
+          bd[g] = 0;
+          best[g] = -1;
+          lo[g] = l0 + g < C ? m.edge_off[l0 + g] : 0x7fffffff;
+          hi[g] = l0 + g < C ? m.edge_off[l0 + g + 1] : 0x7fffffff;
+        }
+        const int e_lo = m.edge_off[l0], e_hi = m.edge_off[l0 + TC_AG < C ? l0 + TC_AG : C];
         for (int w = 0; w < nwin_e; w++) {
           const int w0 = w * K * TC_NT;
-          if (w0 >= eend || w0 + K * TC_NT <= eo) continue;  // no edge of this layer in the window
-          if (!single && w != cur_w) {
-            cache_edges(mc, m, w0, m.total_edges, 0, tid);
-            cur_w = w;
-          }
+          if (w0 >= e_hi || w0 + K * TC_NT <= e_lo) continue;  // no edge of this layer group in the window
+          if (!single) cache_edges(mc, m, w0, m.total_edges, 0, tid);
 #pragma unroll
-          for (int k = 0; k < K; k++) {  // layer.py:43 over this lane's edges of layer l (ascending index)
+          for (int k = 0; k < K; k++) {
             const int e = (w * K + k) * TC_NT + tid;
-            if (e >= eo && e < eend) {
-              double d = tc_fabs(dn[mc.ed[k].x] + dn[mc.ed[k].y]);
-              if (best < 0 || d < bd) {
-                best = e - eo;
-                bd = d;
+            if (e >= e_lo && e < e_hi) {
+              const double d = tc_fabs(dn[mc.ed[k].x] + dn[mc.ed[k].y]);
+#pragma unroll
+              for (int g = 0; g < TC_AG; g++) {
+                const bool take = e >= lo[g] && e < hi[g] && (best[g] < 0 || d < bd[g]);
+                bd[g] = take ? d : bd[g];
+                best[g] = take ? e - lo[g] : best[g];
               }
             }
           }
         }
-        wave_argmin(bd, best);
-        if (tid == l) my_e = best;
+        wave_argmin_group(bd, best);
+#pragma unroll
+        for (int g = 0; g < TC_AG; g++)
+          if (tid == l0 + g) my_e = best[g];
       }
       TSTAMP(15);
       if (tid < C) {
@@ -642,7 +707,12 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
           const int ge = m.edge_off[l] + my_e;
           int2 ed = m.edges_g[ge];
           double2 n0 = m.nodes[ed.x], n1 = m.nodes[ed.y];
-          if (d_within_bounds(n0.x, n0.y, n1.x, n1.y, m.ori_fwd[ge], m.ori_rev[ge], s.x, s.y)) {
+          // layer.py:126-142 by the sign of two dot products; the literal atan2 form only for the lanes (if any) whose
+          // angle is within 1e-6 rad of the pi/2 threshold
+          bool certain;
+          bool inb = d_within_bounds_filter(n0.x, n0.y, n1.x, n1.y, s.x, s.y, certain);
+          if (!certain) inb = d_within_bounds(n0.x, n0.y, n1.x, n1.y, m.ori_fwd[ge], m.ori_rev[ge], s.x, s.y);
+          if (inb) {
             dist_l = tc_fabs(d_distance_to_edge(n0.x, n0.y, n1.x, n1.y, s.x, s.y));
           } else {
             double da = d_dist(s.x, s.y, n0.x, n0.y);
@@ -677,9 +747,40 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
   }
 
   TSTAMP(3);
-  // ---- phase C: camera (camera.py:52-110) + raster (renderer.py:36-51)
-  if ((flags & TC_F_NO_OBSERVATION) || b.obs == nullptr) return false;
-  if (flags & DBG_SKIP_CAMERA) return false;
+  // what the camera stage needs.  car.py:159-165 takes cos(-theta), sin(-theta): tc_cos is exactly even and tc_sin
+  // exactly odd (their kernels are built from x*x and x*y terms only), so the values of the front-axle update are
+  // reused bit for bit.
+  fp.x = s.x;
+  fp.y = s.y;
+  if (have_trig) {
+    fp.cth = s.cth;
+    fp.sth = -s.sth;
+  } else {
+    fp.cth = tc_cos(-s.theta);
+    fp.sth = tc_sin(-s.theta);
+  }
+}
+
+// Phase C, the camera (camera.py:52-110) of one frame: transform -> 4 clip passes -> project -> visibility -> draw list
+// (row `seg_row` of the per-env lists).  Depends on the env's state only through `fp`, so a frame can be produced by the
+// wavefront that simulated the step or by any other one later.  mc_loaded: `mc` already holds the whole map's window
+// (the simulate stage of the same wavefront loaded it).
+template <int K>
+__device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, int env, const FramePose& fp, MapCache<K>& mc,
+                                         const bool mc_loaded, const int tid, const int seg_row) {
+  const DevMap& m = a.m;
+  const int nwin_n = (m.total_nodes + TC_NT * K - 1) / (TC_NT * K), nwin_e = (m.total_edges + TC_NT * K - 1) / (TC_NT * K);
+  const bool single = a.n_grp == 1 && nwin_n <= 1 && nwin_e <= 1;
+  if (single && !mc_loaded) {
+    cache_nodes(mc, m, 0, m.total_nodes, tid);
+    cache_edges(mc, m, 0, m.total_edges, 0, tid);
+  }
+  double* Px = (double*)(smem + a.lds.off_p);
+  double* Py = Px + a.cap_nodes;
+  double* Pz = Py + a.cap_nodes;
+  unsigned char* flg = smem + a.lds.off_flg;
+  int* list = (int*)(smem + a.lds.off_list);
+  int* cnt = (int*)(smem + a.lds.off_cnt);
   const DevCam& cam = a.cam;
   double pose[12], Kc[9];
   {
@@ -688,21 +789,15 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     for (int i = 0; i < 12; i++) Ec[i] = a.cam_E ? a.cam_E[(size_t)env * 12 + i] : cam.E[i];
 #pragma unroll
     for (int i = 0; i < 9; i++) Kc[i] = a.cam_K ? a.cam_K[(size_t)env * 9 + i] : cam.K[i];
-    // car.py:159-165 needs cos(-theta), sin(-theta).  tc_cos is exactly even and tc_sin exactly odd (their kernels
-    // are built from x*x and x*y terms only), so the values of the front-axle update are reused bit for bit.
-    double cth, sth;
-    if (have_trig) {
-      cth = s.cth;
-      sth = -s.sth;
-    } else {
-      cth = tc_cos(-s.theta);
-      sth = tc_sin(-s.theta);
-    }
+    const double cth = fp.cth, sth = fp.sth;
     double R[16] = {cth, -sth, 0, 0, sth, cth, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    double Tm[16] = {1, 0, 0, -s.x, 0, 1, 0, -s.y, 0, 0, 1, 0, 0, 0, 0, 1};
+    double Tm[16] = {1, 0, 0, -fp.x, 0, 1, 0, -fp.y, 0, 0, 1, 0, 0, 0, 0, 1};
     double car3d[16];
     d_matmul<4, 4, 4>(R, Tm, car3d);
     d_matmul<3, 4, 4>(Ec, car3d, pose);  // camera.py:62
+    // the 12 entries are the same in every lane: kept in scalar registers through the node loop (24 VGPRs less)
+#pragma unroll
+    for (int i = 0; i < 12; i++) pose[i] = uni_d(pose[i]);
   }
   // The lane-line layers of a camera group are processed together: node ids are made global (edges_g) and then
   // relative to the group, so each of the passes below is ONE loop over the group's nodes / edges instead of one
@@ -711,7 +806,8 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
   // number of workgroups a CU can hold) is sized by the largest group instead of the whole map.
   // counters: cnt[0..3] fix-up passes, cnt[4] projection candidates, cnt[5] draw list
   int* seg_cnt = cnt + 5;
-  int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;  // [seg_cap][5]: layer, x0, y0, x1, y1
+  const size_t seg_slot = (size_t)seg_row * a.N + env;
+  int* segg = a.seg_g + seg_slot * a.seg_cap * 5;  // [seg_cap][5]: layer, x0, y0, x1, y1
   if (tid == 5) cnt[5] = 0;
   for (int g = 0; g < a.n_grp; g++) {
     const int l0 = a.grp_layer[g], l1 = a.grp_layer[g + 1];
@@ -743,16 +839,19 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     }
     __syncthreads();
     TSTAMP(4);
-    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, true, -0.0000001, list, cnt + 0, tid);   // camera.py:71-74
-    TSTAMP(17);
-    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 1, false, -0.0000001, list, cnt + 1, tid);  // camera.py:75-77
-    TSTAMP(18);
-    for (int i = tid; i < nn; i += TC_NT)
-      if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
-    __syncthreads();
-    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, true, -cam.max_range, list, cnt + 2, tid);   // camera.py:81-83
-    TSTAMP(19);
-    cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, 2, false, -cam.max_range, list, cnt + 3, tid);  // camera.py:84-86
+    // camera.py:71-74, 75-77 (plane z = -1e-7, flag idx_front), then 81-83, 84-86 (plane z = -max_range, flag
+    // idx_in_range): ONE inlined copy of the pass, looped -- four copies were ~4 k instructions of the kernel
+#pragma nounroll
+    for (int pass = 0; pass < 4; pass++) {
+      if (pass == 2) {
+        for (int i = tid; i < nn; i += TC_NT)
+          if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
+        __syncthreads();
+      }
+      cam_fixup_pass(mc, m, reload, ge0, ne, gn0, nwe, Px, Py, Pz, flg, pass < 2 ? 1 : 2, (pass & 1) == 0,
+                     pass < 2 ? -0.0000001 : -cam.max_range, list, cnt + pass, tid);
+      if (pass < 3) TSTAMP(17 + pass);
+    }
     TSTAMP(5);
     // Only nodes in front AND in range can be "visible" (camera.py:92-93): compact them so the two f64
     // divisions of the projection are paid for those nodes only.
@@ -798,13 +897,17 @@ __device__ __forceinline__ bool sim_body(const KArgs& a, unsigned char* smem, in
     __syncthreads();  // the next group reuses the node buffer and the counters
   }
   TSTAMP(7);
-  if (tid == 0) a.seg_n[env] = *seg_cnt;  // handed to the raster stage through global memory
-  return true;
+  if (tid == 0) a.seg_n[seg_slot] = *seg_cnt;  // handed to the raster stage through global memory
 }
 
 // Step k of a launch reads row k of the action arrays and writes row k of the rollout arrays ([nsteps][N] each).
 struct MultiArgs {
   int nsteps;
+  int seg_rows;  // > 1: step k writes its draw list to row k of seg_g / seg_n ([seg_rows][N] lists) for a raster launch
+                 // over all (step, env) frames behind this kernel; 1: row 0 every step (same wavefront rasterises it)
+  int cam_here;  // tc_env_kernel: 1 = the camera stage (draw list) runs in this kernel, 0 = not (no observation wanted,
+                 // or tc_frame_kernel produces the frames from pose_rows)
+  double* pose_rows;  // [nsteps][N][4] (x, y, cos(-theta), sin(-theta)) of every step for tc_frame_kernel, or NULL
   tc_rollout roll;
 };
 __device__ __forceinline__ RollStep roll_at(const tc_rollout& r, size_t row0) {
@@ -837,6 +940,10 @@ struct RArgs {
   const unsigned char* mask;  // reset mask (NULL = all envs)
   int off_tab, off_bits;
   unsigned int flags;
+  // raster launches over several steps' frames (grid.y = frames rows): row blockIdx.y reads draw list row seg_row0 +
+  // blockIdx.y and writes its frame obs_row_stride bytes behind the previous row's
+  int seg_row0;
+  long long obs_row_stride;
 };
 
 #ifndef TC_RASTER_WAVES
@@ -844,11 +951,11 @@ struct RArgs {
 #endif
 template <bool THICK, int FMT>
 __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem, int env, unsigned char* obs_base,
-                                            const int tid) {
+                                            const int tid, const size_t seg_slot0) {
   const RCam& cam = a.cam;
   unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
-  const int* segg = a.seg_g + (size_t)env * a.seg_cap * 5;
-  const int nseg = a.seg_n[env];
+  const int* segg = a.seg_g + (seg_slot0 + env) * a.seg_cap * 5;
+  const int nseg = a.seg_n[seg_slot0 + env];
   TSTAMP(8);
   unsigned int used_layers = 0;  // layers that have at least one segment in this frame (wave-uniform)
   for (int k = tid; k < nseg; k += TC_NT) used_layers |= 1u << segg[5 * k];
@@ -1136,6 +1243,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
     __syncthreads();
   }
   TSTAMP(13);
+  TSTAMP_REAL(31);
 }
 
 template <bool THICK, int FMT>
@@ -1144,7 +1252,10 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
   const int env = a.env0 + blockIdx.x;
   if (env >= a.N) return;
   if (a.mask && !a.mask[env]) return;
-  raster_body<THICK, FMT>(a, smem, env, a.obs, threadIdx.x);
+  // one workgroup per (frame row, env): with more frames than resident workgroups the dispatcher hands the next frame
+  // to whichever slot frees up first, so light and heavy frames balance out across the chip
+  const size_t slot0 = (size_t)(a.seg_row0 + blockIdx.y) * a.N;
+  raster_body<THICK, FMT>(a, smem, env, a.obs + (size_t)blockIdx.y * a.obs_row_stride, threadIdx.x, slot0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1343,7 +1454,15 @@ __device__ __forceinline__ const StepArgs& step_args() {
   return *(const StepArgs*)(StepArgsConst)p;
 }
 
-template <int K>
+__device__ __forceinline__ bool wants_frame(const StepArgs& sa) {
+  return !(sa.flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && (sa.a.b.obs != nullptr || sa.ma.roll.obs != nullptr);
+}
+
+// Simulate stage alone: the steps' state recurrence (phases A + B) with the env's state parked in LDS between steps.
+// What becomes of the frames is the launch's choice: nothing (no observation), the camera stage here and a raster
+// launch behind (cam_here; maps of the K = 13 variant, TC_FUSE=0), or -- the K-step default -- only the poses, from which
+// tc_frame_kernel produces every (step, env) frame as a workgroup of its own.
+template <int K, bool CAM>
 __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) void tc_env_kernel(StepArgs sa_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   const StepArgs& s0 = step_args();
@@ -1352,24 +1471,68 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) vo
   if (s0.mode == MODE_RESET && s0.mask && !s0.mask[env]) return;  // whole workgroup skips
   live_in(s0.a, smem, env, s0.mode, s0.flags);
   const int nsteps = s0.ma.nsteps;
-  for (int k = 0; k < nsteps; k++) {  // nsteps > 1 only without a raster launch behind this one (TC_F_NO_OBSERVATION)
+  for (int k = 0; k < nsteps; k++) {
     const StepArgs& sa = step_args();  // re-read per step: see step_args()
     const size_t esz = sa.cdtype == TC_F32 ? 4 : 8;
     const size_t row0 = (size_t)k * sa.a.N;
+    const int seg_row = sa.ma.seg_rows > 1 ? k : 0;
+    const int tid = step_lane();
+    MapCache<K> mc = {};  // (initialised: a path that leaves it unset would otherwise make it a loop-carried value -- 30
+                          // registers per lane held across the whole step body, raster stage included)
+    FramePose fp;
     sim_body<K>(sa.a, smem, env, sa.mode, (const char*)sa.car_control + row0 * 2 * esz, sa.cdtype, sa.maneuver + row0,
-                sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), step_lane());
+                sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), tid, mc, fp);
+    if (sa.ma.pose_rows && tid < 4) {
+      double v = fp.x;
+      v = tid == 1 ? fp.y : v;
+      v = tid == 2 ? fp.cth : v;
+      v = tid == 3 ? fp.sth : v;
+      step_args().ma.pose_rows[(row0 + env) * 4 + tid] = v;
+    }
+    if (CAM && sa.ma.cam_here) {
+      if (wants_frame(sa))
+        cam_body<K>(sa.a, smem, env, fp, mc, sa.mode != MODE_RENDER, tid, seg_row);  // (tc_render skips phase B's fetch)
+      else if (tid == 0)
+        step_args().a.seg_n[(size_t)seg_row * sa.a.N + env] = 0;
+    }
     __syncthreads();  // the next step reads the LiveLds record this one wrote
   }
   const StepArgs& s1 = step_args();
   if (s1.mode != MODE_RENDER) live_out(s1.a, smem, env);
 }
 
-// Both stages in one launch: the same wavefront simulates its env and then rasterises it.  Saves one kernel
-// boundary (launch gap + one ramp-up / drain of the whole grid) per step.
-// tc_step_multi: the wavefront stays with its env for nsteps steps (envs are independent: no grid-wide synchronisation
-// between steps).  The map cache, kernel arguments and tables are fetched once per launch instead of once per step, the
-// env's state stays on chip (LDS) between steps, and the wavefronts of a SIMD drift apart, so that they no longer sit
-// in the same latency-bound phase at the same time and no step pays a grid ramp-up or waits for the slowest env.
+// One (step, env) frame per workgroup: camera stage from the pose the simulate launch left, then the raster stage.
+// Frames do not depend on each other, a launch has steps x N of them -- many more than the chip holds at once -- and
+// their cost varies 8-fold with what is in view, so the dispatcher's hand-out of the next frame to the next free slot is
+// what balances the load (a wavefront that keeps an env for the whole launch inherits that env's view instead).
+struct FrameArgs {
+  KArgs a;
+  RArgs r;
+  const double* pose_rows;  // [rows][N][4]
+};
+template <int K, bool THICK, int FMT>
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame_kernel(FrameArgs fa) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int env = fa.a.env0 + blockIdx.x;
+  if (env >= fa.a.N) return;
+  const int tid = threadIdx.x;
+  const int row = fa.r.seg_row0 + blockIdx.y;
+  const size_t slot0 = (size_t)row * fa.a.N;
+  const double* pr = fa.pose_rows + (slot0 + env) * 4;
+  FramePose fp;
+  fp.x = pr[0];
+  fp.y = pr[1];
+  fp.cth = pr[2];
+  fp.sth = pr[3];
+  MapCache<K> mc;
+  cam_body<K>(fa.a, smem, env, fp, mc, false, tid, row);
+  __syncthreads();  // draw list + count written by this wavefront are visible to it (vmcnt(0) + barrier)
+  raster_body<THICK, FMT>(fa.r, smem, env, fa.r.obs + (size_t)blockIdx.y * fa.r.obs_row_stride, tid, slot0);
+}
+
+// All stages in one launch: the same wavefront simulates its env, runs the camera and rasterises the frame.  The form
+// of tc_step / tc_reset / tc_render (one step: nothing to balance, and one kernel boundary less), and of tc_step_multi
+// under TC_MULTI_SPLIT=0.
 template <int K, bool THICK, int FMT>
 __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_kernel(StepArgs sa_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1384,14 +1547,20 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
     const size_t esz = sa.cdtype == TC_F32 ? 4 : 8;
     const size_t row0 = (size_t)k * sa.a.N;
     const int tid = step_lane();
-    const bool draw = sim_body<K>(sa.a, smem, env, sa.mode, (const char*)sa.car_control + row0 * 2 * esz, sa.cdtype,
-                                  sa.maneuver + row0, sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), tid);
-    __syncthreads();  // draw list + count written by this wavefront are visible to it (vmcnt(0) + barrier)
-    if (draw) {
+    MapCache<K> mc = {};  // (initialised: a path that leaves it unset would otherwise make it a loop-carried value -- 30
+                          // registers per lane held across the whole step body, raster stage included)
+    FramePose fp;
+    sim_body<K>(sa.a, smem, env, sa.mode, (const char*)sa.car_control + row0 * 2 * esz, sa.cdtype, sa.maneuver + row0,
+                sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), tid, mc, fp);
+    if (wants_frame(sa)) {
+      cam_body<K>(sa.a, smem, env, fp, mc, sa.mode != MODE_RENDER, tid, 0);  // (tc_render skips phase B's fetch)
+      __syncthreads();  // draw list + count written by this wavefront are visible to it (vmcnt(0) + barrier)
       const StepArgs& sb = step_args();
       const size_t obs_step = sb.ma.roll.obs ? (size_t)sb.a.N * ((size_t)sb.r.cam.H * sb.r.cam.W * (FMT == TC_FMT_CLASSES ? sb.r.C : 3)) : 0;
       unsigned char* obs_base = sb.ma.roll.obs ? sb.ma.roll.obs : sb.r.obs;
-      raster_body<THICK, FMT>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid);
+      raster_body<THICK, FMT>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid, 0);
+    } else {
+      __syncthreads();  // the next step reads the LiveLds record this one wrote
     }
   }
   const StepArgs& s1 = step_args();
@@ -1408,6 +1577,17 @@ static fused_kern_t pick_fused(bool thick, bool cls) {
 #else
   return thick ? (cls ? tc_step_kernel<K, true, TC_FMT_CLASSES> : tc_step_kernel<K, true, TC_FMT_RGB>)
                : (cls ? tc_step_kernel<K, false, TC_FMT_CLASSES> : tc_step_kernel<K, false, TC_FMT_RGB>);
+#endif
+}
+
+typedef void (*frame_kern_t)(FrameArgs);
+template <int K>
+static frame_kern_t pick_frame(bool thick, bool cls) {
+#ifdef TC_DEV_FAST
+  return tc_frame_kernel<5, true, TC_FMT_CLASSES>;
+#else
+  return thick ? (cls ? tc_frame_kernel<K, true, TC_FMT_CLASSES> : tc_frame_kernel<K, true, TC_FMT_RGB>)
+               : (cls ? tc_frame_kernel<K, false, TC_FMT_CLASSES> : tc_frame_kernel<K, false, TC_FMT_RGB>);
 #endif
 }
 
@@ -1447,6 +1627,16 @@ struct tc_env {
   // the overlap gains, so it stays off.
   int split;
   int fuse;  // 1: simulate + raster in one launch (tc_step_kernel); 0: two launches
+  // tc_step_multi with observations, split form (default; TC_MULTI_SPLIT=0 selects the fused K-step kernel): ONE
+  // simulate launch loops over the K steps and leaves K draw lists per env, ONE raster launch of K x N workgroups
+  // draws them.  Why: a frame costs between ~10 k clocks (nothing in view) and ~80 k (60 segments) to rasterise and an
+  // env keeps its kind of view for many steps, so in the fused K-step kernel the launch lasts as long as its heaviest
+  // env (measured on cfg3: 70.9 us per step against a mean of 41 us per wavefront-step).  Frames are independent of
+  // each other, and K x N workgroups are many more than the chip holds at once, so the dispatcher balances them.
+  int multi_split;
+  int *segm_g, *segm_n;  // [segm_rows][N][seg_cap][5], [segm_rows][N]
+  double* pose_rows;     // [segm_rows][N][4]
+  int segm_rows;
   int kvar;  // register-cache slots of the simulate stage: 5, 8 (whole map in one window), 9 (camera layer groups), 13
   hipStream_t side[TC_MAX_SPLIT];
   hipEvent_t fork_ev, join_ev[TC_MAX_SPLIT];
@@ -1653,6 +1843,11 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   e->split = 1;
   e->fuse = 1;
   if (const char* fu = getenv("TC_FUSE")) e->fuse = atoi(fu) != 0;
+  e->multi_split = 1;
+  if (const char* ms = getenv("TC_MULTI_SPLIT")) e->multi_split = atoi(ms) != 0;
+  e->segm_g = e->segm_n = nullptr;
+  e->pose_rows = nullptr;
+  e->segm_rows = 0;
   if (const char* sp = getenv("TC_SPLIT")) {
     int v = atoi(sp);
     if (v >= 1 && v <= TC_MAX_SPLIT) e->split = v;
@@ -1786,6 +1981,9 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
           (void)hipFuncSetAttribute((const void*)pick_fused<5>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_fused<8>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_fused<9>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          (void)hipFuncSetAttribute((const void*)pick_frame<5>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          (void)hipFuncSetAttribute((const void*)pick_frame<8>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          (void)hipFuncSetAttribute((const void*)pick_frame<9>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
     }
   }
@@ -1797,10 +1995,11 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
     (void)hipFuncSetAttribute((const void*)tc_raster_kernel<false, TC_FMT_RGB>, hipFuncAttributeMaxDynamicSharedMemorySize, e->r_lds);
   }
   if (L.total > 48 * 1024) {
-    hipError_t he = hipFuncSetAttribute((const void*)tc_env_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    if (he == hipSuccess) he = hipFuncSetAttribute((const void*)tc_env_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    if (he == hipSuccess) he = hipFuncSetAttribute((const void*)tc_env_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    if (he == hipSuccess) he = hipFuncSetAttribute((const void*)tc_env_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    hipError_t he = hipSuccess;
+    const void* ek[8] = {(const void*)tc_env_kernel<5, true>,  (const void*)tc_env_kernel<8, true>,  (const void*)tc_env_kernel<9, true>,
+                         (const void*)tc_env_kernel<13, true>, (const void*)tc_env_kernel<5, false>, (const void*)tc_env_kernel<8, false>,
+                         (const void*)tc_env_kernel<9, false>, (const void*)tc_env_kernel<13, false>};
+    for (int i = 0; i < 8 && he == hipSuccess; i++) he = hipFuncSetAttribute(ek[i], hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (he != hipSuccess) {
       set_err(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he));
       delete e;
@@ -1869,6 +2068,9 @@ extern "C" int tc_env_destroy(tc_env* e) {
     }
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
   }
+  if (e && e->segm_g) (void)hipFree(e->segm_g);
+  if (e && e->segm_n) (void)hipFree(e->segm_n);
+  if (e && e->pose_rows) (void)hipFree(e->pose_rows);
   if (e && e->k.seg_g) (void)hipFree(e->k.seg_g);
   if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
   if (e && e->k.terms) (void)hipFree((void*)e->k.terms);
@@ -2155,6 +2357,8 @@ static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_c
   r.off_tab = e->r_off_tab;
   r.off_bits = e->r_off_bits;
   r.flags = flags;
+  r.seg_row0 = 0;
+  r.obs_row_stride = 0;
   return r;
 }
 
@@ -2209,10 +2413,13 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   const bool prof = e->prof > 0 && mode == MODE_STEP && (e->prof_calls++ % e->prof) == 0;
   const int slot = e->prof_n % TC_PROF_RING;
   const int kv = e->kvar;
+  // simulate stage alone, with or without the camera stage compiled in (without: fewer registers, half the code)
 #ifdef TC_DEV_FAST
-  auto kern = tc_env_kernel<5>;
+  auto kern = tc_env_kernel<5, true>;
+  auto kern_nocam = tc_env_kernel<5, false>;
 #else
-  auto kern = kv == 5 ? tc_env_kernel<5> : kv == 8 ? tc_env_kernel<8> : kv == 9 ? tc_env_kernel<9> : tc_env_kernel<13>;
+  auto kern = kv == 5 ? tc_env_kernel<5, true> : kv == 8 ? tc_env_kernel<8, true> : kv == 9 ? tc_env_kernel<9, true> : tc_env_kernel<13, true>;
+  auto kern_nocam = kv == 5 ? tc_env_kernel<5, false> : kv == 8 ? tc_env_kernel<8, false> : kv == 9 ? tc_env_kernel<9, false> : tc_env_kernel<13, false>;
 #endif
   const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && (e->k.b.obs || (roll && roll->obs));
   const int N = e->k.N;
@@ -2225,6 +2432,92 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   hipStream_t main = (hipStream_t)stream;
   if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], main));
   if (parts > 1) HIP_TRY(hipEventRecord(e->fork_ev, main));
+  if (do_raster && nsteps > 1 && (e->multi_split || !e->fuse || kv == 13)) {
+    // K steps, split form: ONE simulate launch over the steps, ONE launch over the frames wanted
+    if (e->segm_rows < nsteps) {
+      HIP_TRY(hipDeviceSynchronize());  // earlier launches may still read the old buffers
+      if (e->segm_g) (void)hipFree(e->segm_g);
+      if (e->segm_n) (void)hipFree(e->segm_n);
+      if (e->pose_rows) (void)hipFree(e->pose_rows);
+      e->segm_g = e->segm_n = nullptr;
+      e->pose_rows = nullptr;
+      e->segm_rows = 0;
+      void *p = nullptr, *q = nullptr, *pr = nullptr;
+      hipError_t he = hipMalloc(&p, (size_t)nsteps * N * e->k.seg_cap * 5 * sizeof(int));
+      if (he == hipSuccess) he = hipMalloc(&q, (size_t)nsteps * N * sizeof(int));
+      if (he == hipSuccess) he = hipMalloc(&pr, (size_t)nsteps * N * 4 * sizeof(double));
+      if (he != hipSuccess) {
+        if (p) (void)hipFree(p);
+        if (q) (void)hipFree(q);
+        set_err(std::string("hipMalloc(per-step buffers of a K-step launch): ") + hipGetErrorString(he));
+        return TC_E_NOMEM;
+      }
+      e->segm_g = (int*)p;
+      e->segm_n = (int*)q;
+      e->pose_rows = (double*)pr;
+      e->segm_rows = nsteps;
+    }
+    const bool frames = e->fuse && kv != 13;  // camera + raster per frame (tc_frame_kernel); else camera in the simulate
+                                              // launch (the register-hungry K = 13 stage, TC_FUSE=0) and a raster launch
+    StepArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.a = e->k;
+    sa.a.env0 = 0;
+    sa.a.seg_g = e->segm_g;
+    sa.a.seg_n = e->segm_n;
+    sa.ma = ma;
+    sa.ma.seg_rows = nsteps;
+    sa.ma.cam_here = frames ? 0 : 1;
+    sa.ma.pose_rows = frames ? e->pose_rows : nullptr;
+    sa.mode = mode;
+    sa.cdtype = cdtype;
+    sa.flags = flags;
+    sa.car_control = cc;
+    sa.maneuver = man;
+    sa.spawn_nodes = spawn;
+    sa.mask = mask;
+    hipLaunchKernelGGL(frames ? kern_nocam : kern, dim3(N), dim3(TC_NT), e->k.lds.total, main, sa);
+    HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
+    // with a rollout every step's frame is wanted; without one only the last survives in the bound buffer
+    const bool all = roll && roll->obs;
+    RArgs r = make_rargs(e, e->segm_g, e->segm_n, e->k.seg_cap, nullptr, flags, 0, all ? roll->obs : nullptr);
+    r.seg_row0 = all ? 0 : nsteps - 1;
+    r.obs_row_stride = all ? (long long)N * (long long)e->obs_bytes : 0;
+    const int rows = all ? nsteps : 1;
+    const bool thick = r.cam.thickness > 1, cls = r.cam.format == TC_FMT_CLASSES;
+    (void)thick;
+    (void)cls;
+    for (int row0 = 0; row0 < rows; row0 += 65535) {  // grid.y limit
+      RArgs rr = r;
+      rr.seg_row0 = r.seg_row0 + row0;
+      rr.obs += (size_t)row0 * (size_t)r.obs_row_stride;
+      const int ny = rows - row0 < 65535 ? rows - row0 : 65535;
+      if (frames) {
+        FrameArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.a = sa.a;
+        fa.r = rr;
+        fa.pose_rows = e->pose_rows;
+        frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
+        hipLaunchKernelGGL(fk, dim3(N, ny), dim3(TC_NT), e->k.lds.total, main, fa);
+      } else {
+#ifdef TC_DEV_FAST
+        auto rk = tc_raster_kernel<true, TC_FMT_CLASSES>;
+#else
+        auto rk = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
+                        : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
+#endif
+        hipLaunchKernelGGL(rk, dim3(N, ny), dim3(TC_NT), e->r_lds, main, rr);
+      }
+      HIP_TRY(hipGetLastError());
+    }
+    if (prof) {
+      HIP_TRY(hipEventRecord(e->ev[2][slot], main));
+      e->prof_n++;
+    }
+    return TC_OK;
+  }
   if (do_raster && e->fuse && parts == 1 && kv != 13) {  // one launch: simulate + raster by the same wavefront
     // (the register-hungry K = 13 simulate stage spills when fused, so it stays two launches)
     const bool thick = e->k.cam.thickness > 1, cls = e->k.cam.format == TC_FMT_CLASSES;
@@ -2265,6 +2558,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     memset(&sa, 0, sizeof(sa));
     sa.a = k;
     sa.ma = ma;
+    sa.ma.cam_here = do_raster ? 1 : 0;
     sa.mode = mode;
     sa.cdtype = cdtype;
     sa.flags = flags;
@@ -2272,7 +2566,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     sa.maneuver = man;
     sa.spawn_nodes = spawn;
     sa.mask = mask;
-    hipLaunchKernelGGL(kern, dim3(env1 - env0), dim3(TC_NT), k.lds.total, st, sa);
+    hipLaunchKernelGGL(do_raster ? kern : kern_nocam, dim3(env1 - env0), dim3(TC_NT), k.lds.total, st, sa);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
     if (do_raster) {
@@ -2310,10 +2604,11 @@ extern "C" int tc_step_multi(tc_env* e, const void* car_control, int32_t control
     return TC_E_UNBOUND;
   }
   const bool want_obs = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && (e->k.b.obs || (rollout && rollout->obs));
-  // one launch for all steps: the fused kernel, or the simulate kernel alone when nothing is rendered
-  const bool one_launch = want_obs ? (e->fuse && e->kvar != 13 && e->noise_blobs == 0) : true;
+  // all steps in one simulate launch (+ one raster launch over the frames, or fused into it: see launch()); only the
+  // stand-alone noise pass still needs one pair of launches per step
+  const bool one_launch = want_obs ? e->noise_blobs == 0 : true;
   if (one_launch) return launch(e, MODE_STEP, car_control, control_dtype, maneuver, nullptr, nullptr, flags, stream, n_steps, rollout);
-  // two-launch maps (and the stand-alone noise pass): one step per pair of launches, rollout rows advanced on the host
+  // (noise pass): one step per group of launches, rollout rows advanced on the host
   const size_t N = (size_t)e->k.N, esz = control_dtype == TC_F32 ? 4 : 8;
   for (int k = 0; k < n_steps; k++) {
     tc_rollout r;
@@ -2333,13 +2628,17 @@ extern "C" int tc_step_multi(tc_env* e, const void* car_control, int32_t control
   return TC_OK;
 }
 
-extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t* fused, int32_t* kvar, char* name, int32_t name_cap) {
+extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar, char* name,
+                                  int32_t name_cap) {
   if (!e) return TC_E_INVALID;
   const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
-  const bool f = fused_path(e, flags) && e->split == 1;
+  const bool f = fused_path(e, flags) && e->split == 1 && !(n_steps > 1 && e->multi_split);
   if (fused) *fused = f ? 1 : 0;
   if (kvar) *kvar = e->kvar;
-  if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", f ? "tc_step_kernel" : do_raster ? "tc_env_kernel+tc_raster_kernel" : "tc_env_kernel");
+  const bool frames = n_steps > 1 && do_raster && !f && e->fuse && e->kvar != 13;
+  if (name && name_cap > 0)
+    snprintf(name, (size_t)name_cap, "%s",
+             f ? "tc_step_kernel" : frames ? "tc_env_kernel+tc_frame_kernel" : do_raster ? "tc_env_kernel+tc_raster_kernel" : "tc_env_kernel");
   return TC_OK;
 }
 

@@ -418,10 +418,11 @@ class TinyCarloVecEnv(gym.Env):
                                               C.byref(r) if rollout else None, self._stream()), "tc_step_multi")
         self._keep = (car_control, maneuver, rollout)
 
-    def launch_info(self) -> Dict[str, Any]:
-        """What a step with the current settings launches (tc_env_launch_info): for benchmark labels."""
+    def launch_info(self, n_steps: int = 1) -> Dict[str, Any]:
+        """What a call of n_steps steps launches with the current settings (tc_env_launch_info): for benchmark labels."""
         f, kv, name = C.c_int32(), C.c_int32(), C.create_string_buffer(64)
-        nat.check(nat.lib().tc_env_launch_info(self._h, self._flags(), C.byref(f), C.byref(kv), name, 64), "tc_env_launch_info")
+        nat.check(nat.lib().tc_env_launch_info(self._h, self._flags(), int(n_steps), C.byref(f), C.byref(kv), name, 64),
+                  "tc_env_launch_info")
         return {"fused": bool(f.value), "kvar": kv.value, "kernel": name.value.decode()}
 
     def request_reset(self, mask: torch.Tensor) -> None:

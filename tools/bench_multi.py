@@ -70,7 +70,7 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / a.steps
         r = {"K": K, "us_per_step": round(us, 2), "env_steps_per_s": round(n / us * 1e6), "envs": n,
              "workload": a.workload, "rollout": a.rollout if K >= 1 else "bound obs",
-             "resets": int(env._aux["spawn_cursor"].sum().item()), "kernel": env.launch_info()}
+             "resets": int(env._aux["spawn_cursor"].sum().item()), "kernel": env.launch_info(max(K, 1))}
         print(json.dumps(r), flush=True)
         res.append(r)
         env.close()

@@ -1,7 +1,8 @@
-cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/gpu_tests.log
-for sp in 1 2 3 4 8; do
-  for w in cfg3 cfg4; do
-  TC_SPLIT=$sp timeout -k 10 200 python bench.py --workload $w --steps 500 --warmup 50 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('split=$sp $w', round(d['roofline']['step_us'],1),'us', round(d['value']/1e6,2),'M/s')"
-  done
+#!/bin/bash
+# dev build (cfg3 kernels only): step_multi parity on simple_layout, then split vs fused K-step launches
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+timeout -k 10 300 python -m pytest tests/test_gpu_step_multi.py -x -q -k "simple_layout-r64-classes or stress or fused_terms or oracle or without_rollout or no_observation or wrap" > gpurun_out/t_multi.log 2>&1; rc=$?; tail -5 gpurun_out/t_multi.log; [ $rc -eq 0 ] || exit 1
+for s in 1 0; do
+  TC_MULTI_SPLIT=$s timeout -k 10 600 python tools/bench_multi.py --steps 1024 --k 8 32 128 2>/dev/null | cut -c1-200 | sed "s/^/split=$s /"
 done

@@ -29,7 +29,8 @@ NAMES = ["entry -> tracking done (phase A)", "state / info write-back", "lane-li
 # (name, from probe, to probe) inside the big phases.  Probes 20-22 sit inside the rasteriser's batch loop (32 segments
 # per batch) and keep the LAST batch's stamps: for frames with more than 32 segments the "setup:" intervals mix batches
 # (the first one then contains a whole batch and the last one goes negative); the first-level table is not affected.
-SUB = [("B: node distances + sync", 2, 14), ("B: 5 x (edge scan + wave argmin)", 14, 15), ("B: per-layer tail (loads, bounds, distance)", 15, 16),
+SUB = [("A: state from LDS, action, kinematics", 0, 23), ("A: lanepath tracking (dependent fat-node loads)", 23, 1),
+       ("B: node distances + sync", 2, 14), ("B: 5 x (edge scan + wave argmin)", 14, 15), ("B: per-layer tail (loads, bounds, distance)", 15, 16),
        ("clip pass 1 (behind -> front)", 4, 17), ("clip pass 2", 17, 18), ("range flags + clip pass 3", 18, 19), ("clip pass 4", 19, 5),
        ("setup: table offsets, segment fetch", 9, 20), ("setup: ThickLine quad (sqrt, div, rounding)", 20, 21),
        ("setup: fill events", 21, 22), ("setup: table writes + sync", 22, 10)]
@@ -40,6 +41,9 @@ def main():
     ap.add_argument("--envs", type=int, nargs="+", default=[64, 4096])
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--multi", type=int, default=0,
+                    help="issue the steps through tc_step_multi, this many per launch (the stamps kept are those of the "
+                         "LAST step of a launch: a wavefront that has been running with desynchronised neighbours)")
     a = ap.parse_args()
     mp, res = ("simple_layout", [64, 64]) if a.workload == "cfg3" else ("knuffingen", [128, 128])
     path = bundled_config(f"config_{mp}.yaml")
@@ -58,26 +62,54 @@ def main():
         acc = np.zeros(13)
         sub = {}
         life = 0.0
+        real = 0.0
+        lives, sims = [], []
         n = 0
         for t in range(a.steps + 10):
-            cc = torch.stack([torch.rand(N, device="cuda:0", generator=g) * 0.7 + 0.3,
-                              torch.rand(N, device="cuda:0", generator=g) * 2 - 1], dim=1)
-            mn = torch.randint(0, 4, (N,), device="cuda:0", generator=g, dtype=torch.int32)
-            env.step_device(cc, mn)
+            if a.multi > 0:
+                K = a.multi
+                cc = torch.stack([torch.rand((K, N), device="cuda:0", generator=g) * 0.7 + 0.3,
+                                  torch.rand((K, N), device="cuda:0", generator=g) * 2 - 1], dim=2).contiguous()
+                mn = torch.randint(0, 4, (K, N), device="cuda:0", generator=g, dtype=torch.int32)
+                env.step_multi(cc, mn)
+            else:
+                cc = torch.stack([torch.rand(N, device="cuda:0", generator=g) * 0.7 + 0.3,
+                                  torch.rand(N, device="cuda:0", generator=g) * 2 - 1], dim=1)
+                mn = torch.randint(0, 4, (N,), device="cuda:0", generator=g, dtype=torch.int32)
+                env.step_device(cc, mn)
             if t < 10:
                 continue
             st = np.zeros((N, 32), dtype=np.int64)
             nat.check(L.tc_debug_tstamp_read(st.ctypes.data, N), "tstamp_read")
-            ok = (st[:, :23] > 0).all(axis=1)          # envs that ran every phase (not re-spawned without info etc.)
+            # envs that ran every phase in THIS step (not re-spawned without info, at least one segment drawn ...): with
+            # several steps per launch a probe a step skipped still holds an older step's stamp, hence the order test
+            ok = (st[:, :24] > 0).all(axis=1) & (np.diff(st[:, :14], axis=1) >= 0).all(axis=1)
+            for name, i0, i1 in SUB:
+                ok &= st[:, i1] >= st[:, i0]
             d = np.diff(st[ok, :14], axis=1)
             acc += d.mean(axis=0)
             life += (st[ok, 13] - st[ok, 0]).mean()
+            every = (st[:, 13] > st[:, 0]) & (st[:, 0] > 0)   # all envs that finished this step, whatever they skipped
+            lives.append((st[every, 13] - st[every, 0]))
+            sims.append((st[every, 7] - st[every, 0]) * (st[every, 7] > st[every, 0]))
+            real += (st[ok, 31] - st[ok, 30]).mean()  # 100 MHz ticks over the same interval
             for name, i0, i1 in SUB:
                 sub[name] = sub.get(name, 0.0) + (st[ok, i1] - st[ok, i0]).mean()
             n += 1
         acc /= n
         life /= n
-        print(f"--- {a.workload}, {N} envs: wavefront lifetime {life:.0f} clocks (mean over envs that ran every phase)")
+        real /= n
+        print(f"    shader clock held while the kernel runs: {life / max(real, 1e-9) * 100:.0f} MHz "
+              f"({life:.0f} shader clocks in {real * 10:.0f} ns of the constant 100 MHz counter)")
+        print(f"--- {a.workload}, {N} envs, {a.multi or 1} step(s) per launch: one step of a wavefront takes {life:.0f} clocks (mean over envs that ran every phase)")
+        lv = np.concatenate(lives).astype(np.float64)
+        sm = np.concatenate(sims).astype(np.float64)
+        q = np.percentile(lv, [1, 10, 50, 90, 99, 100])
+        print("    step time over ALL envs (clocks): p1 %.0f  p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f  mean %.0f"
+              % (*q, lv.mean()))
+        slow = lv >= q[4]
+        print("    slowest 1 %%: simulate part %.0f, raster part %.0f clocks;  fastest 10 %%: simulate %.0f, raster %.0f"
+              % (sm[slow].mean(), (lv - sm)[slow].mean(), sm[lv <= q[1]].mean(), (lv - sm)[lv <= q[1]].mean()))
         for name, v in zip(NAMES, acc):
             print(f"  {name:52s} {v:9.0f}  {100 * v / life:5.1f} %")
         print("  second level:")
