@@ -160,6 +160,9 @@ def main():
                     help="untimed steps issued for about this long before the warm-up so that a short run is measured at "
                          "steady clocks (reported as config.preroll_steps)")
     ap.add_argument("--no-gathered", action="store_true", help="--gpus > 1: skip the gathered measurements")
+    ap.add_argument("--no-rollout", action="store_true",
+                    help="diagnostic: K-step launches without per-step rollout rows (only the last step's outputs and frame "
+                         "are stored; NOT the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=int, default=2000000, help="env-steps of the all-cores CPU baseline sample")
     args = ap.parse_args()
@@ -207,7 +210,9 @@ def main():
         period = max(M, period // M * M)  # a multiple of the launch size: launches do not straddle the wrap-around
     cc, man = gen_actions(n, period, seed=rank, device=device)
     roll = None
-    if M >= 1 and not w["no_obs"]:
+    if args.no_rollout:
+        pass
+    elif M >= 1 and not w["no_obs"]:
         roll = env.alloc_rollout(M, keys=("obs", "reward", "terminated", "truncated"))
     elif M >= 1:
         roll = env.alloc_rollout(M, keys=("reward", "terminated", "truncated"))
@@ -233,7 +238,7 @@ def main():
                 if sink is not None:
                     sink.launch(cc[i:i + kk], man[i:i + kk])
                 else:
-                    r = roll if kk == M else {k_: v[:kk] for k_, v in roll.items()}
+                    r = None if roll is None else (roll if kk == M else {k_: v[:kk] for k_, v in roll.items()})
                     env.step_multi(cc[i:i + kk], man[i:i + kk], rollout=r)
                 t += kk
                 want -= kk

@@ -25,7 +25,33 @@
 
 // Timing build only (make timing -> libtinycarlo_hip_timing.so, used by tools/phase_clock.py): every wavefront stores
 // the shader clock at its phase boundaries.  The shipped library is compiled without TC_TIMING and contains none of it.
-#ifdef TC_TIMING
+#if defined(TC_TIMING) && defined(TC_TIMING_LOOP)
+// variant of the timing build (make dev-timing-loop): no phase probes, only the period of every step of a K-step launch
+// (slot k = clocks from the top of step k-1 to the top of step k, k < 32; slot 0 = launch entry -> top of step 0)
+__device__ long long* tc_tstamp = nullptr;
+#define TSTAMP(i) \
+  do {            \
+  } while (0)
+#define TSTAMP_REAL(i) \
+  do {                 \
+  } while (0)
+#define TSTAMP_LOOP(k, nsteps, tprev)                                                      \
+  do {                                                                                     \
+    long long _t = clock64();                                                              \
+    long long* _tp = tc_tstamp;                                                            \
+    if (_tp && threadIdx.x == 0 && (k) < 31) _tp[(size_t)env * 32 + (k)] = _t - (tprev);  \
+    (tprev) = _t;                                                                          \
+  } while (0)
+#define TSTAMP_END(tprev)                                                                  \
+  do {                                                                                     \
+    long long* _tp = tc_tstamp;                                                            \
+    if (_tp && threadIdx.x == 0) {                                                         \
+      _tp[(size_t)env * 32 + 31] = clock64() - (tprev);                                    \
+      _tp[(size_t)env * 32 + 30] = (long long)(unsigned)__builtin_amdgcn_s_getreg(63492) | /* HW_REG_HW_ID */ \
+                                   ((long long)(unsigned)__builtin_amdgcn_s_getreg(63508) << 32); /* XCC_ID */ \
+    }                                                                                      \
+  } while (0)
+#elif defined(TC_TIMING)
 __device__ long long* tc_tstamp = nullptr;  // [N][32]
 // (outstanding memory operations are drained first, so a phase is charged with the latencies it started)
 #define TSTAMP(i)                                                                          \
@@ -36,10 +62,21 @@ __device__ long long* tc_tstamp = nullptr;  // [N][32]
   } while (0)
 // the constant 100 MHz counter next to the shader clock: (stamp 13 - stamp 0) / (stamp 31 - stamp 30) x 100 MHz is the
 // clock the chip actually holds while the kernel runs
+// loop period of the step loop: slot 28 = clocks from the top of the previous step to the top of the last one
+#define TSTAMP_LOOP(k, nsteps, tprev)                                                      \
+  do {                                                                                     \
+    long long _t = clock64();                                                              \
+    long long* _tp = tc_tstamp;                                                            \
+    if (_tp && threadIdx.x == 0 && (k) == (nsteps)-1 && (k) > 0) _tp[(size_t)env * 32 + 28] = _t - (tprev); \
+    (tprev) = _t;                                                                          \
+  } while (0)
 #define TSTAMP_REAL(i)                                                                     \
   do {                                                                                     \
     long long* _tp = tc_tstamp;                                                            \
     if (_tp && threadIdx.x == 0) _tp[(size_t)env * 32 + (i)] = wall_clock64();            \
+  } while (0)
+#define TSTAMP_END(tprev) \
+  do {                    \
   } while (0)
 #else
 #define TSTAMP(i) \
@@ -47,6 +84,12 @@ __device__ long long* tc_tstamp = nullptr;  // [N][32]
   } while (0)
 #define TSTAMP_REAL(i) \
   do {                 \
+  } while (0)
+#define TSTAMP_LOOP(k, nsteps, tprev) \
+  do {                                \
+  } while (0)
+#define TSTAMP_END(tprev) \
+  do {                    \
   } while (0)
 #endif
 
@@ -747,6 +790,7 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
   }
 
   TSTAMP(3);
+  TSTAMP_REAL(29);
   // what the camera stage needs.  car.py:159-165 takes cos(-theta), sin(-theta): tc_cos is exactly even and tc_sin
   // exactly odd (their kernels are built from x*x and x*y terms only), so the values of the front-axle update are
   // reused bit for bit.
@@ -767,7 +811,9 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
 // (the simulate stage of the same wavefront loaded it).
 template <int K>
 __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, int env, const FramePose& fp, MapCache<K>& mc,
-                                         const bool mc_loaded, const int tid, const int seg_row) {
+                                         const bool mc_loaded, const int tid, const int seg_row, int& nseg_out,
+                                         unsigned int& used_out) {
+  unsigned int my_layers = 0;  // layers this lane put a segment into the draw list for
   const DevMap& m = a.m;
   const int nwin_n = (m.total_nodes + TC_NT * K - 1) / (TC_NT * K), nwin_e = (m.total_edges + TC_NT * K - 1) / (TC_NT * K);
   const bool single = a.n_grp == 1 && nwin_n <= 1 && nwin_e <= 1;
@@ -853,19 +899,38 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
       if (pass < 3) TSTAMP(17 + pass);
     }
     TSTAMP(5);
-    // Only nodes in front AND in range can be "visible" (camera.py:92-93): compact them so the two f64
-    // divisions of the projection are paid for those nodes only.
+    // Only nodes in front AND in range can be "visible" (camera.py:92-93), and an edge is drawn when one of its ends is
+    // (camera.py:95) -- with the pixel coordinates of BOTH ends.  So the nodes worth projecting (two f64 divisions each)
+    // are the ends of edges that have an end in front and in range: mark them, compact them, project them in one
+    // lane-parallel pass.  (Projecting the far ends inside the draw-list loop instead made the whole wavefront run the
+    // projection code in every edge slot in which a single lane needed it.)
+    for (int w = 0; w < nwe; w++) {
+      if (reload) cache_edges(mc, m, ge0 + w * K * TC_NT, ge0 + ne, gn0, tid);
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const int e = (w * K + k) * TC_NT + tid;
+        if (e < ne) {
+          const int2 ed = mc.ed[k];
+          const int fa = flg[ed.x], fb = flg[ed.y];
+          if ((fa & 3) == 3 || (fb & 3) == 3) {  // (lanes sharing a node write the same value: nothing else changes here)
+            flg[ed.x] = (unsigned char)(fa | 16);
+            flg[ed.y] = (unsigned char)(fb | 16);
+          }
+        }
+      }
+    }
+    __syncthreads();
     for (int i = tid; i < nn; i += TC_NT)
-      if ((flg[i] & 3) == 3) list[atomicAdd(cnt + 4, 1)] = i;
+      if (flg[i] & 16) list[atomicAdd(cnt + 4, 1)] = i;
     __syncthreads();
     const int ncand = cnt[4];
     for (int k = tid; k < ncand; k += TC_NT) {  // camera.py:133-142, 90
       const int i = list[k];
       double u, v;
       int2 q = cam_project(Kc, Px[i], Py[i], Pz[i], u, v);
-      bool vis = (u > 0) && (u < cam.W) && (v > 0) && (v < cam.H);
+      const bool vis = (u > 0) && (u < cam.W) && (v > 0) && (v < cam.H) && (flg[i] & 3) == 3;
       ((int2*)Px)[i] = q;  // renderer.py:43,50 np.int32(...)
-      flg[i] |= vis ? (4 | 8) : 8;  // 8: slot Px[i] now holds the int32 pixel coordinates
+      if (vis) flg[i] |= 4;
     }
     __syncthreads();
     TSTAMP(6);
@@ -876,13 +941,11 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
         const int e = (w * K + k) * TC_NT + tid;
         if (e < ne) {
           const int2 ed = mc.ed[k];
-          const int fa = flg[ed.x], fb = flg[ed.y];
-          if ((fa | fb) & 4) {
-            double u, v;
-            int2 pa = (fa & 8) ? ((int2*)Px)[ed.x] : cam_project(Kc, Px[ed.x], Py[ed.x], Pz[ed.x], u, v);
-            int2 pb = (fb & 8) ? ((int2*)Px)[ed.y] : cam_project(Kc, Px[ed.y], Py[ed.y], Pz[ed.y], u, v);
+          if ((flg[ed.x] | flg[ed.y]) & 4) {  // a visible end: both ends were marked above and hold pixel coordinates
+            const int2 pa = ((int2*)Px)[ed.x], pb = ((int2*)Px)[ed.y];
             int layer = l0;
             for (int c = l0 + 1; c < l1; c++) layer += (ge0 + e) >= m.edge_off[c];
+            my_layers |= 1u << layer;
             int j = atomicAdd(seg_cnt, 1);
             int* o = segg + 5 * j;  // j < seg_cap == total edge count
             o[0] = layer;
@@ -897,7 +960,11 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
     __syncthreads();  // the next group reuses the node buffer and the counters
   }
   TSTAMP(7);
-  if (tid == 0) a.seg_n[seg_slot] = *seg_cnt;  // handed to the raster stage through global memory
+  nseg_out = uni_i(*seg_cnt);
+  if (tid == 0) a.seg_n[seg_slot] = nseg_out;  // (for a raster launch of its own; the same wavefront gets it in a register)
+  used_out = 0;
+  for (int c = 0; c < m.C; c++)
+    if (__ballot((my_layers >> c) & 1u)) used_out |= 1u << c;
 }
 
 // Step k of a launch reads row k of the action arrays and writes row k of the rollout arrays ([nsteps][N] each).
@@ -951,16 +1018,23 @@ struct RArgs {
 #endif
 template <bool THICK, int FMT>
 __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem, int env, unsigned char* obs_base,
-                                            const int tid, const size_t seg_slot0) {
+                                            const int tid, const size_t seg_slot0, const int nseg_in,
+                                            const unsigned int used_in) {
   const RCam& cam = a.cam;
   unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
   const int* segg = a.seg_g + (seg_slot0 + env) * a.seg_cap * 5;
-  const int nseg = a.seg_n[seg_slot0 + env];
+  // draw-list length and the layers that have a segment in this frame (wave-uniform): handed over in registers by the
+  // camera stage of the same wavefront, or read back when this is a launch of its own (nseg_in < 0)
+  int nseg = nseg_in;
+  unsigned int used_layers = used_in;
   TSTAMP(8);
-  unsigned int used_layers = 0;  // layers that have at least one segment in this frame (wave-uniform)
-  for (int k = tid; k < nseg; k += TC_NT) used_layers |= 1u << segg[5 * k];
+  if (nseg_in < 0) {
+    nseg = a.seg_n[seg_slot0 + env];
+    used_layers = 0;
+    for (int k = tid; k < nseg; k += TC_NT) used_layers |= 1u << segg[5 * k];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) used_layers |= __shfl_xor(used_layers, off);
+    for (int off = 32; off > 0; off >>= 1) used_layers |= __shfl_xor(used_layers, off);
+  }
 
   const int H = cam.H, W = cam.W, wpr = cam.wpr, C = a.C;
   unsigned char* out = obs_base + (size_t)env * ((size_t)H * W * (FMT == TC_FMT_CLASSES ? C : 3));
@@ -1255,7 +1329,7 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
   // one workgroup per (frame row, env): with more frames than resident workgroups the dispatcher hands the next frame
   // to whichever slot frees up first, so light and heavy frames balance out across the chip
   const size_t slot0 = (size_t)(a.seg_row0 + blockIdx.y) * a.N;
-  raster_body<THICK, FMT>(a, smem, env, a.obs + (size_t)blockIdx.y * a.obs_row_stride, threadIdx.x, slot0);
+  raster_body<THICK, FMT>(a, smem, env, a.obs + (size_t)blockIdx.y * a.obs_row_stride, threadIdx.x, slot0, -1, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1315,14 +1389,16 @@ __global__ __launch_bounds__(TC_NT) void tc_noise_kernel(NArgs a) {
     } else {
       bl = tc_noise_blob(a.seed, (uint32_t)env, *a.step, (uint32_t)k, W, H, a.max_radius, C);
     }
-    // caller-provided lists are not trusted with LDS indices: an invalid row becomes a blob that touches nothing
+    // caller-provided lists are not trusted with LDS indices: an invalid row becomes a blob that touches nothing.
+    // src only matters on the copy branch: erase blobs carry src = -1 in the reference's draw order (nothing is drawn
+    // for them, observation.py:25-26) and must stay erasers.
     const bool ok = bl.r >= 1 && bl.r < a.max_radius && (unsigned)bl.x < (unsigned)W && (unsigned)bl.y < (unsigned)H &&
-                    (unsigned)bl.src < (unsigned)C;
+                    (bl.mode == 0 || (unsigned)bl.src < (unsigned)C);
     lb[5 * k] = bl.x;
     lb[5 * k + 1] = bl.y;
     lb[5 * k + 2] = ok ? bl.r : -1;
     lb[5 * k + 3] = bl.mode;
-    lb[5 * k + 4] = ok ? bl.src : 0;
+    lb[5 * k + 4] = (ok && bl.mode != 0) ? bl.src : 0;
   }
   __syncthreads();
   for (int k = 0; k < nb; k++) {  // row k of lhw = row r_k of the table, entries 0 .. r_k
@@ -1465,13 +1541,36 @@ __device__ __forceinline__ bool wants_frame(const StepArgs& sa) {
 template <int K, bool CAM>
 __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) void tc_env_kernel(StepArgs sa_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // Touching v127 makes the kernel descriptor ask for 128 VGPRs, i.e. caps the SIMD at the 4 wavefronts the launch
+  // needs (N = 4096 one-wavefront workgroups = 4 per SIMD).  The camera-less variant uses 74 registers and would fit 6,
+  // and the dispatcher does fill SIMDs that unevenly: measured, wavefronts on the crowded SIMDs took 54 k clocks per
+  // step against 27 k on the sparse ones, and a K-step launch lasts as long as its slowest wavefront (580 us, median
+  // wavefront 420 us).  (amdgpu_waves_per_eu(4, 4) next to __launch_bounds__ did not raise the allocation.)
+  asm volatile("v_mov_b32 v127, 0" ::: "v127");
   const StepArgs& s0 = step_args();
   const int env = s0.a.env0 + blockIdx.x;
   if (env >= s0.a.N) return;
   if (s0.mode == MODE_RESET && s0.mask && !s0.mask[env]) return;  // whole workgroup skips
   live_in(s0.a, smem, env, s0.mode, s0.flags);
   const int nsteps = s0.ma.nsteps;
+  long long t_prev = 0;
+#ifdef TC_TIMING
+  t_prev = clock64();
+#endif
+  (void)t_prev;
+  // The 4 wavefronts of a SIMD compete for its vector issue slots, and at equal priority the arbiter favours the OLDEST
+  // one: measured over a 30-step launch, a step took the oldest wavefront 27 k clocks and the youngest 54 k, so the
+  // launch lasted 550 us while the median wavefront was done after 420.  Rotating the priority with the step index
+  // (each wavefront is on top every 4th step) lets the four progress at the same average rate and finish together.
+  const int wave_slot = (int)(__builtin_amdgcn_s_getreg(63492) & 15u);  // HW_REG_HW_ID.wave_id: distinct on a SIMD
   for (int k = 0; k < nsteps; k++) {
+    TSTAMP_LOOP(k, nsteps, t_prev);
+    switch ((k + wave_slot) & 3) {  // (s_setprio takes an immediate)
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
     const StepArgs& sa = step_args();  // re-read per step: see step_args()
     const size_t esz = sa.cdtype == TC_F32 ? 4 : 8;
     const size_t row0 = (size_t)k * sa.a.N;
@@ -1490,13 +1589,17 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) vo
       step_args().ma.pose_rows[(row0 + env) * 4 + tid] = v;
     }
     if (CAM && sa.ma.cam_here) {
-      if (wants_frame(sa))
-        cam_body<K>(sa.a, smem, env, fp, mc, sa.mode != MODE_RENDER, tid, seg_row);  // (tc_render skips phase B's fetch)
+      if (wants_frame(sa)) {
+        int nseg;
+        unsigned int used;
+        cam_body<K>(sa.a, smem, env, fp, mc, sa.mode != MODE_RENDER, tid, seg_row, nseg, used);  // (tc_render skips phase B's fetch)
+      }
       else if (tid == 0)
         step_args().a.seg_n[(size_t)seg_row * sa.a.N + env] = 0;
     }
     __syncthreads();  // the next step reads the LiveLds record this one wrote
   }
+  TSTAMP_END(t_prev);
   const StepArgs& s1 = step_args();
   if (s1.mode != MODE_RENDER) live_out(s1.a, smem, env);
 }
@@ -1525,9 +1628,11 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame
   fp.cth = pr[2];
   fp.sth = pr[3];
   MapCache<K> mc;
-  cam_body<K>(fa.a, smem, env, fp, mc, false, tid, row);
-  __syncthreads();  // draw list + count written by this wavefront are visible to it (vmcnt(0) + barrier)
-  raster_body<THICK, FMT>(fa.r, smem, env, fa.r.obs + (size_t)blockIdx.y * fa.r.obs_row_stride, tid, slot0);
+  int nseg;
+  unsigned int used;
+  cam_body<K>(fa.a, smem, env, fp, mc, false, tid, row, nseg, used);
+  __syncthreads();  // draw list written by this wavefront is visible to it (vmcnt(0) + barrier)
+  raster_body<THICK, FMT>(fa.r, smem, env, fa.r.obs + (size_t)blockIdx.y * fa.r.obs_row_stride, tid, slot0, nseg, used);
 }
 
 // All stages in one launch: the same wavefront simulates its env, runs the camera and rasterises the frame.  The form
@@ -1542,7 +1647,13 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
   if (s0.mode == MODE_RESET && s0.mask && !s0.mask[env]) return;  // whole workgroup skips
   live_in(s0.a, smem, env, s0.mode, s0.flags);
   const int nsteps = s0.ma.nsteps;
+  long long t_prev = 0;
+#ifdef TC_TIMING
+  t_prev = clock64();
+#endif
+  (void)t_prev;
   for (int k = 0; k < nsteps; k++) {
+    TSTAMP_LOOP(k, nsteps, t_prev);
     const StepArgs& sa = step_args();  // re-read per step: see step_args()
     const size_t esz = sa.cdtype == TC_F32 ? 4 : 8;
     const size_t row0 = (size_t)k * sa.a.N;
@@ -1553,16 +1664,19 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
     sim_body<K>(sa.a, smem, env, sa.mode, (const char*)sa.car_control + row0 * 2 * esz, sa.cdtype, sa.maneuver + row0,
                 sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), tid, mc, fp);
     if (wants_frame(sa)) {
-      cam_body<K>(sa.a, smem, env, fp, mc, sa.mode != MODE_RENDER, tid, 0);  // (tc_render skips phase B's fetch)
-      __syncthreads();  // draw list + count written by this wavefront are visible to it (vmcnt(0) + barrier)
+      int nseg;
+      unsigned int used;
+      cam_body<K>(sa.a, smem, env, fp, mc, sa.mode != MODE_RENDER, tid, 0, nseg, used);  // (tc_render skips phase B's fetch)
+      __syncthreads();  // draw list written by this wavefront is visible to it (vmcnt(0) + barrier)
       const StepArgs& sb = step_args();
       const size_t obs_step = sb.ma.roll.obs ? (size_t)sb.a.N * ((size_t)sb.r.cam.H * sb.r.cam.W * (FMT == TC_FMT_CLASSES ? sb.r.C : 3)) : 0;
       unsigned char* obs_base = sb.ma.roll.obs ? sb.ma.roll.obs : sb.r.obs;
-      raster_body<THICK, FMT>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid, 0);
+      raster_body<THICK, FMT>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid, 0, nseg, used);
     } else {
       __syncthreads();  // the next step reads the LiveLds record this one wrote
     }
   }
+  TSTAMP_END(t_prev);
   const StepArgs& s1 = step_args();
   if (s1.mode != MODE_RENDER) live_out(s1.a, smem, env);
 }

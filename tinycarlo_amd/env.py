@@ -186,7 +186,7 @@ class TinyCarloEnv(gym.Env):
     def _info(self) -> Dict[str, Any]:  # env.py:83-85
         v = self._vec
         st, o = v.state, v.out
-        valid = int(o["nearest_edge"][0, 0].item()) >= 0
+        valid = int(st["lp_len"][0].item()) >= 2  # car.py:47-51 (not nearest_edge[0]: layer 0 may have no edges)
         pos = [float(st["x"][0].item()), float(st["y"][0].item())]
         if not valid:  # car.py:47-51
             return {"cte": 0, "heading_error": 0, "position": pos, "orientation": float(st["theta"][0].item()),

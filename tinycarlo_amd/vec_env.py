@@ -492,7 +492,10 @@ class TinyCarloVecEnv(gym.Env):
     def _info(self) -> Dict[str, Any]:
         """Batched version of env.py:83-85.  `local_path` is [N,4,2] (rows past `local_path_len` are 0)."""
         st, o = self.state, self.out
-        valid = o["nearest_edge"][:, 0] >= 0                      # car.get_info returned real values
+        # car.get_info returned real values (car.py:47-51): the local path has its look-ahead edges.  A freshly
+        # (re)spawned env has lp_len == 1, and so has one whose tracking stopped early (truncated).  (Not read off
+        # nearest_edge[:, 0]: a first lane-line layer without edges would report -1 there for ever.)
+        valid = st["lp_len"] >= 2
         n = torch.where(valid, st["lp_len"], torch.zeros_like(st["lp_len"]))
         idx = st["local_path"][:, 1::2].long().clamp(min=0)
         coords = self._lp_nodes[idx]                              # nodes[edge[1]] per edge (car.py:66)

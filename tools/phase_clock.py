@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--envs", type=int, nargs="+", default=[64, 4096])
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--bench-actions", action="store_true", help="the action stream of bench.py (maneuver held for 64 steps)")
+    ap.add_argument("--no-obs", action="store_true",
+                    help="no_observation: the simulate kernel alone (phases A + B), as the first launch of a K-step call runs it")
     ap.add_argument("--multi", type=int, default=0,
                     help="issue the steps through tc_step_multi, this many per launch (the stamps kept are those of the "
                          "LAST step of a launch: a wavefront that has been running with desynchronised neighbours)")
@@ -57,16 +60,29 @@ def main():
     for N in a.envs:
         nat.check(L.tc_debug_tstamp_alloc(N), "tstamp_alloc")   # before ANY launch of this batch size
         env = TinyCarloVecEnv(cfg, num_envs=N, device="cuda:0", autoreset=True)
+        env.no_observation = a.no_obs
         env.reset(seed=0)
         g = torch.Generator(device="cuda:0").manual_seed(0)
         acc = np.zeros(13)
         sub = {}
         life = 0.0
         real = 0.0
-        lives, sims = [], []
+        lives, sims, ab = [], [], []
         n = 0
         for t in range(a.steps + 10):
-            if a.multi > 0:
+            if a.multi > 0 and a.bench_actions:
+                import bench
+                K = a.multi
+                if t == 0:
+                    cc_all, mn_all = bench.gen_actions(N, K * (a.steps + 10), seed=0, device=torch.device("cuda:0"))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                env.step_multi(cc_all[t * K:(t + 1) * K], mn_all[t * K:(t + 1) * K])
+                e1.record()
+                torch.cuda.synchronize()
+                if t >= 10:
+                    print(f"    launch {t}: {e0.elapsed_time(e1) * 1e3:.0f} us for {K} steps")
+            elif a.multi > 0:
                 K = a.multi
                 cc = torch.stack([torch.rand((K, N), device="cuda:0", generator=g) * 0.7 + 0.3,
                                   torch.rand((K, N), device="cuda:0", generator=g) * 2 - 1], dim=2).contiguous()
@@ -81,6 +97,17 @@ def main():
                 continue
             st = np.zeros((N, 32), dtype=np.int64)
             nat.check(L.tc_debug_tstamp_read(st.ctypes.data, N), "tstamp_read")
+            if a.no_obs:  # probes 0, 23, 1, 2, 14, 15, 16, 3 only
+                seq = [0, 23, 1, 2, 14, 15, 16, 3]
+                ok = (st[:, seq] > 0).all(axis=1) & (np.diff(st[:, seq], axis=1) >= 0).all(axis=1)
+                d = np.diff(st[ok][:, seq], axis=1).astype(np.float64)
+                ab.append(d)
+                lives.append(st[ok, 3] - st[ok, 0])
+                sims.append(st[ok, 28])   # loop period: top of the previous step -> top of the last step
+                life += (st[ok, 3] - st[ok, 0]).mean()
+                real += (st[ok, 29] - st[ok, 30]).mean()  # 100 MHz ticks from probe 0 to probe 3
+                n += 1
+                continue
             # envs that ran every phase in THIS step (not re-spawned without info, at least one segment drawn ...): with
             # several steps per launch a probe a step skipped still holds an older step's stamp, hence the order test
             ok = (st[:, :24] > 0).all(axis=1) & (np.diff(st[:, :14], axis=1) >= 0).all(axis=1)
@@ -99,6 +126,21 @@ def main():
         acc /= n
         life /= n
         real /= n
+        if a.no_obs:
+            dd = np.concatenate(ab)
+            lv = np.concatenate(lives).astype(np.float64)
+            print(f"--- {a.workload} no_observation, {N} envs, {a.multi or 1} step(s) per launch: phases A + B of one step take {life:.0f} clocks")
+            print(f"    shader clock held while the kernel runs: {life / max(real, 1e-9) * 100:.0f} MHz "
+                  f"({life:.0f} shader clocks in {real * 10:.0f} ns of the constant 100 MHz counter)")
+            print("    step time over envs (clocks): p1 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(lv, [1, 50, 90, 99, 100])))
+            pr = np.concatenate(sims).astype(np.float64)
+            print("    loop period, step k-1 top -> step k top (clocks): mean %.0f p50 %.0f p99 %.0f max %.0f" % (pr.mean(), *np.percentile(pr, [50, 99, 100])))
+            for nm, v in zip(["A: state from LDS, action, kinematics", "A: lanepath tracking", "write-back", "B: map window + node distances",
+                              "B: edge scan + argmins", "B: per-layer tail", "terms / end"], dd.mean(axis=0)):
+                print(f"  {nm:52s} {v:9.0f}")
+            env.close()
+            nat.check(L.tc_debug_tstamp_alloc(0), "tstamp_free")
+            continue
         print(f"    shader clock held while the kernel runs: {life / max(real, 1e-9) * 100:.0f} MHz "
               f"({life:.0f} shader clocks in {real * 10:.0f} ns of the constant 100 MHz counter)")
         print(f"--- {a.workload}, {N} envs, {a.multi or 1} step(s) per launch: one step of a wavefront takes {life:.0f} clocks (mean over envs that ran every phase)")
