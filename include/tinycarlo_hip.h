@@ -194,12 +194,14 @@ int tc_env_set_terms(tc_env* env, const tc_term* terms, int32_t n_terms, int32_t
 int tc_env_set_spawn_table(tc_env* env, const int32_t* nodes, int32_t n, uint64_t seed);
 /* NoiseObservationWrapper (wrapper/observation.py:5-33) for class-mask observations: per class plane n_blobs blobs,
  * each a filled circle (centre inside the frame, radius in [1, max_radius)) that either erases the plane inside the
- * circle or ORs in the circle-masked content of a random plane, applied in order.  With n_blobs > 0 every tc_step
- * that renders an observation is followed by the noise kernel on the same stream, blobs drawn on the device
+ * circle or ORs in the circle-masked content of a random plane, applied in order.  With n_blobs > 0 every tc_step /
+ * tc_step_multi that renders an observation applies the blobs inside the raster stage, on the frame's bit-planes in
+ * LDS before they are expanded to bytes (no extra pass over the observation in HBM), blobs drawn on the device
  * (tinycarlo_amd/csrc/tc_rng.h; the reference draws from the global numpy generator, which cannot be reproduced
- * for a batch).  The position in the blob stream is a counter in device memory advanced on the stream after every
- * device-drawn pass, so a tc_step captured into a HIP graph draws new blobs on every replay.  n_blobs = 0 switches the
- * noise off.  Needs TC_FMT_CLASSES and max_radius in [2, 256]. */
+ * for a batch).  Every rendered step consumes one position of the blob stream; the position is a counter in device
+ * memory advanced on the stream behind the launch, so a call captured into a HIP graph draws new blobs on every
+ * replay.  tc_reset / tc_render frames carry no noise (the reference's reset() does not pass through the wrapper's
+ * step()).  n_blobs = 0 switches the noise off.  Needs TC_FMT_CLASSES and max_radius in [2, 256]. */
 int tc_env_set_noise(tc_env* env, int32_t n_blobs, int32_t max_radius, uint64_t seed);
 /* The noise pass alone, on the currently bound observation.  blobs: device int32 [N][n_layers * n_blobs][5] rows
  * (x, y, radius, mode, src) -- blob k belongs to plane k / n_blobs, mode 1 = copy from plane src, 0 = erase -- or

@@ -208,3 +208,35 @@ def test_multi_argument_checks():
     with pytest.raises(ValueError):
         env.step_multi(cc, man, rollout={"obs": torch.zeros(3, 8, 1, dtype=torch.uint8, device="cuda:0")})
     env.close()
+
+
+def test_multi_with_fused_noise_equals_single_steps():
+    """NoiseObservationWrapper fused into the raster stage: step k of a K-step launch draws the blobs of stream position
+    base + k, exactly as the k-th of K single steps does -- rollout rows and the blob counter afterwards identical"""
+    n, K = 96, 9
+    multi, single = _twin("simple_layout", "r64", "classes", n, autoreset=True)
+    for e in (multi, single):
+        e.wrapped = True
+        e.set_noise(10, 100, seed=123)   # the reference's defaults (wrapper/observation.py:9)
+    cc, man = _actions(n, K, seed=31)
+    roll = multi.alloc_rollout(K, keys=("obs", "reward"))
+    multi.step_multi(cc, man, rollout=roll)
+    clean = make_env("simple_layout", "r64", "classes", n, autoreset=True)
+    clean.wrapped = True
+    clean.reset(seed=3)
+    differs = 0
+    for k in range(K):
+        single.step_device(cc[k], man[k])
+        clean.step_device(cc[k], man[k])
+        torch.cuda.synchronize()
+        assert torch.equal(roll["obs"][k], single.out["obs"]), ("noised obs row", k, int((roll["obs"][k] != single.out["obs"]).sum()))
+        differs += int((single.out["obs"] != clean.out["obs"]).any())
+    assert differs == K, "the noise left frames untouched"
+    # a second launch continues the blob stream where the first one stopped
+    multi.step_multi(cc[:3], man[:3], rollout={"obs": roll["obs"][:3]})
+    for k in range(3):
+        single.step_device(cc[k], man[k])
+        torch.cuda.synchronize()
+        assert torch.equal(roll["obs"][k], single.out["obs"]), ("second launch", k)
+    for e in (multi, single, clean):
+        e.close()

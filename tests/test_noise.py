@@ -148,6 +148,33 @@ def test_gpu_noise_kernel_equals_oracle_on_given_blobs(res, n_blobs, max_r):
 
 
 @pytest.mark.gpu
+def test_gpu_apply_noise_takes_the_wrappers_own_rows():
+    """draw_blobs() writes src = -1 on the erase branch (nothing is drawn for it in the reference).  Those rows, passed
+    unchanged to apply_noise / tc_noise, must erase -- not be dropped as invalid (they were: ~70 % of the blobs)."""
+    from tinycarlo_amd.wrapper.observation import apply_blobs, draw_blobs
+    N, n_blobs, max_r = 8, 10, 100
+    env = _hip_env("simple_layout", (64, 64), N)
+    C = env.n_classes
+    env.set_noise(n_blobs, max_r, seed=0)
+    rng = np.random.default_rng(11)
+    frames = ((rng.random((N, C, 64, 64)) < 0.3).astype(np.uint8) * 255)
+    np.random.seed(5)
+    blobs = np.array([draw_blobs(C, 64, 64, n_blobs, max_r) for _ in range(N)], dtype=np.int32)
+    assert (blobs[:, :, 4] == -1).sum() > N * C * n_blobs // 2 and (blobs[:, :, 3] == 1).sum() > 0
+    env.out["obs"].copy_(torch.from_numpy(frames))
+    got = env.apply_noise(blobs)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    for i in range(N):
+        want = apply_blobs(frames[i].copy(), [list(map(int, b)) for b in blobs[i]], n_blobs)
+        assert np.array_equal(got[i], want), (i, int((got[i] != want).sum()))
+        want_o = orc.noise_classes(frames[i].copy(), np.maximum(blobs[i], [0, 0, 0, 0, 0]), n_blobs)
+        assert np.array_equal(got[i], want_o), i
+    assert (got != frames).sum() > 1000
+    env.close()
+
+
+@pytest.mark.gpu
 def test_gpu_step_with_noise_equals_oracle():
     """tc_env_set_noise: every rendering step is followed by the noise kernel with device-drawn blobs (step counter
     0, 1, 2, ...), fused and two-launch step paths, knuffingen's 128x128 planes; NoiseObservationWrapper on the HIP env"""

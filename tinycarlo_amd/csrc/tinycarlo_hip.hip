@@ -1011,6 +1011,12 @@ struct RArgs {
   // blockIdx.y and writes its frame obs_row_stride bytes behind the previous row's
   int seg_row0;
   long long obs_row_stride;
+  // NoiseObservationWrapper fused into the raster stage (class masks only): blobs per plane (0 = off), radius bound,
+  // the per-radius span table and the blob stream (position of frame row 0 = *noise_step)
+  int noise_blobs, noise_max_radius;
+  const unsigned char* noise_hw;
+  unsigned long long noise_seed;
+  const unsigned int* noise_step;
 };
 
 #ifndef TC_RASTER_WAVES
@@ -1019,7 +1025,7 @@ struct RArgs {
 template <bool THICK, int FMT>
 __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem, int env, unsigned char* obs_base,
                                             const int tid, const size_t seg_slot0, const int nseg_in,
-                                            const unsigned int used_in) {
+                                            const unsigned int used_in, const int frame_row) {
   const RCam& cam = a.cam;
   unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
   const int* segg = a.seg_g + (seg_slot0 + env) * a.seg_cap * 5;
@@ -1197,6 +1203,73 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
       }
     }
     __syncthreads();
+    if (FMT == TC_FMT_CLASSES && a.noise_blobs > 0) {
+      // NoiseObservationWrapper (wrapper/observation.py:15-27) on the bit-planes, before they are expanded: the frame
+      // never makes the extra round trip through HBM a pass of its own costs (71 us per step on cfg3 in round 1).
+      // Every operation of the reference is per pixel -- plane c |= plane src & circle, or plane c &= ~circle, blob
+      // after blob, plane after plane -- so one lane owns one (row, 32-pixel word) of ALL planes and replays the whole
+      // blob sequence on it: no lane ever reads a word another lane writes, no barrier between blobs.  Plane c's word
+      // lives in a register while its n_blobs are applied; planes < c are read back noised, planes > c as rasterised,
+      // exactly the sequential order.  A filled cv2.circle with its centre inside the image is, row by row, the span
+      // centre +- hw[radius][|row - cy|] clipped to the image (see tc_noise_kernel).
+      const int nbl = a.noise_blobs, nb = C * nbl, mr = a.noise_max_radius;
+      int* bp = (int*)(smem + R_OFF_TAB);                 // [nb][2] (x | y << 16), (r | mode << 12 | src << 16): the
+      unsigned char* bh = (unsigned char*)(bp + 2 * nb);  // raster tables are dead here;  [nb][rows] half widths
+      const bool staged = nb * 8 + nb * rows <= R_TAB_BYTES;
+      const unsigned int nstep = *a.noise_step + (unsigned int)frame_row;
+      for (int k = tid; k < nb; k += TC_NT) {
+        const tc_blob bl = tc_noise_blob(a.noise_seed, (uint32_t)env, nstep, (uint32_t)k, W, H, mr, C);
+        bp[2 * k] = bl.x | (bl.y << 16);
+        bp[2 * k + 1] = bl.r | (bl.mode << 12) | (bl.src << 16);
+      }
+      __syncthreads();
+      if (staged) {  // half width of every (blob, row of this band): one table byte each, fetched with the loads in flight
+        for (int row = tid; row < rows; row += TC_NT) {
+#pragma unroll 5
+          for (int k = 0; k < nb; k++) {
+            const int by = bp[2 * k] >> 16, rr = bp[2 * k + 1] & 0xfff;
+            int t = y0 + row - by;
+            t = t < 0 ? -t : t;
+            bh[k * rows + row] = t <= rr ? a.noise_hw[rr * mr + t] : (unsigned char)0;
+          }
+        }
+        __syncthreads();
+      }
+      const int items = rows * wpr;
+      for (int it = tid; it < items; it += TC_NT) {
+        const int row = it / wpr, w = it - row * wpr;
+        const int yy = y0 + row, x_lo = w << 5;
+        for (int c = 0; c < C; c++) {
+          unsigned int cur = bits[(c * cam.band_rows + row) * wpr + w];
+          for (int j = 0; j < nbl; j++) {
+            const int k = c * nbl + j;
+            const int p0 = bp[2 * k], p1 = bp[2 * k + 1];
+            const int bx = p0 & 0xffff, by = p0 >> 16, rr = p1 & 0xfff, src = p1 >> 16;
+            int t = yy - by;
+            t = t < 0 ? -t : t;
+            if (t <= rr) {
+              const int hwv = staged ? (int)bh[k * rows + row] : (int)a.noise_hw[rr * mr + t];
+              int xl = bx - hwv, xr = bx + hwv;
+              xl = xl < 0 ? 0 : xl;
+              xr = xr > W - 1 ? W - 1 : xr;
+              const int b0 = xl > x_lo ? xl - x_lo : 0, b1 = xr < x_lo + 31 ? xr - x_lo : 31;
+              if (b1 >= b0) {
+                const unsigned int mask = (0xffffffffu >> (31 - b1)) & (0xffffffffu << b0);
+                if ((p1 >> 12) & 1) {  // observation.py:22-24
+                  const unsigned int sw = src == c ? cur : bits[(src * cam.band_rows + row) * wpr + w];
+                  cur |= sw & mask;
+                } else {
+                  cur &= ~mask;  // observation.py:26
+                }
+              }
+            }
+          }
+          bits[(c * cam.band_rows + row) * wpr + w] = cur;
+        }
+      }
+      __syncthreads();
+      used_layers = C >= 32 ? 0xffffffffu : ((1u << C) - 1u);  // a copy may have filled a plane that had no segment
+    }
     TSTAMP(12);
     if (a.flags & DBG_SKIP_STORE) {
     } else if (FMT == TC_FMT_CLASSES) {
@@ -1329,7 +1402,7 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
   // one workgroup per (frame row, env): with more frames than resident workgroups the dispatcher hands the next frame
   // to whichever slot frees up first, so light and heavy frames balance out across the chip
   const size_t slot0 = (size_t)(a.seg_row0 + blockIdx.y) * a.N;
-  raster_body<THICK, FMT>(a, smem, env, a.obs + (size_t)blockIdx.y * a.obs_row_stride, threadIdx.x, slot0, -1, 0u);
+  raster_body<THICK, FMT>(a, smem, env, a.obs + (size_t)blockIdx.y * a.obs_row_stride, threadIdx.x, slot0, -1, 0u, a.seg_row0 + (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1352,7 +1425,7 @@ struct NArgs {
   unsigned int inv_cpr;  // 2^32 / (W / 16) + 1, for fdiv by the 16-pixel chunks per row
 };
 
-__global__ void tc_noise_tick(unsigned int* step) { *step += 1; }
+__global__ void tc_noise_tick(unsigned int* step, unsigned int n) { *step += n; }
 
 // q / d for q < 2^31 with inv = 2^32 / d + 1 (host): one multiply-high and a fix-up instead of a ~30-instruction
 // runtime division (as first written this kernel spent most of its ~12 k instructions per wavefront dividing indices)
@@ -1632,7 +1705,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame
   unsigned int used;
   cam_body<K>(fa.a, smem, env, fp, mc, false, tid, row, nseg, used);
   __syncthreads();  // draw list written by this wavefront is visible to it (vmcnt(0) + barrier)
-  raster_body<THICK, FMT>(fa.r, smem, env, fa.r.obs + (size_t)blockIdx.y * fa.r.obs_row_stride, tid, slot0, nseg, used);
+  raster_body<THICK, FMT>(fa.r, smem, env, fa.r.obs + (size_t)blockIdx.y * fa.r.obs_row_stride, tid, slot0, nseg, used, row);
 }
 
 // All stages in one launch: the same wavefront simulates its env, runs the camera and rasterises the frame.  The form
@@ -1671,7 +1744,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
       const StepArgs& sb = step_args();
       const size_t obs_step = sb.ma.roll.obs ? (size_t)sb.a.N * ((size_t)sb.r.cam.H * sb.r.cam.W * (FMT == TC_FMT_CLASSES ? sb.r.C : 3)) : 0;
       unsigned char* obs_base = sb.ma.roll.obs ? sb.ma.roll.obs : sb.r.obs;
-      raster_body<THICK, FMT>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid, 0, nseg, used);
+      raster_body<THICK, FMT>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid, 0, nseg, used, k);
     } else {
       __syncthreads();  // the next step reads the LiveLds record this one wrote
     }
@@ -2341,7 +2414,7 @@ static int launch_noise(tc_env* e, const int32_t* blobs, void* stream, uint8_t* 
   hipLaunchKernelGGL(tc_noise_kernel, dim3(n.N), dim3(TC_NT), noise_lds_bytes(e), (hipStream_t)stream, n);
   HIP_TRY(hipGetLastError());
   if (!blobs) {  // device-drawn blobs consumed one position of the stream
-    hipLaunchKernelGGL(tc_noise_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, e->noise_step);
+    hipLaunchKernelGGL(tc_noise_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, e->noise_step, 1u);
     HIP_TRY(hipGetLastError());
   }
   return TC_OK;
@@ -2435,7 +2508,7 @@ extern "C" int tc_env_set_camera(tc_env* e, const tc_camera_params* cam) {
 }
 
 static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
-                        int env0, uint8_t* obs = nullptr) {
+                        int env0, uint8_t* obs = nullptr, bool with_noise = false) {
   RArgs r;
   memset(&r, 0, sizeof(r));
   r.N = e->k.N;
@@ -2473,18 +2546,25 @@ static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_c
   r.flags = flags;
   r.seg_row0 = 0;
   r.obs_row_stride = 0;
+  if (with_noise && e->noise_blobs > 0 && c.format == TC_FMT_CLASSES) {
+    r.noise_blobs = e->noise_blobs;
+    r.noise_max_radius = e->noise_max_radius;
+    r.noise_hw = e->noise_hw;
+    r.noise_seed = e->noise_seed;
+    r.noise_step = e->noise_step;
+  }
   return r;
 }
 
 static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_cap, const uint8_t* mask, uint32_t flags,
-                         void* stream, int env0 = 0, int count = -1, uint8_t* obs = nullptr) {
+                         void* stream, int env0 = 0, int count = -1, uint8_t* obs = nullptr, bool with_noise = false) {
 #ifdef TC_TIMING
   if (g_tstamp && e->k.N > g_tstamp_n) {
     set_err("timing build: the installed stamp buffer is smaller than this env batch");
     return TC_E_INVALID;
   }
 #endif
-  RArgs r = make_rargs(e, seg_g, seg_n, seg_cap, mask, flags, env0, obs);
+  RArgs r = make_rargs(e, seg_g, seg_n, seg_cap, mask, flags, env0, obs, with_noise);
   if (count < 0) count = e->k.N;
 #ifdef TC_DEV_FAST
   auto kern = tc_raster_kernel<true, TC_FMT_CLASSES>;
@@ -2495,6 +2575,15 @@ static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_
 #endif
   hipLaunchKernelGGL(kern, dim3(count), dim3(TC_NT), e->r_lds, (hipStream_t)stream, r);
   HIP_TRY(hipGetLastError());
+  return TC_OK;
+}
+
+static int noise_advance(tc_env* e, int mode, bool rendered, int nsteps, void* stream) {
+  // the fused noise consumed one position of the blob stream per step of this launch
+  if (rendered && mode == MODE_STEP && e->noise_blobs > 0 && e->k.cam.format == TC_FMT_CLASSES) {
+    hipLaunchKernelGGL(tc_noise_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, e->noise_step, (unsigned int)nsteps);
+    HIP_TRY(hipGetLastError());
+  }
   return TC_OK;
 }
 
@@ -2595,7 +2684,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
     // with a rollout every step's frame is wanted; without one only the last survives in the bound buffer
     const bool all = roll && roll->obs;
-    RArgs r = make_rargs(e, e->segm_g, e->segm_n, e->k.seg_cap, nullptr, flags, 0, all ? roll->obs : nullptr);
+    RArgs r = make_rargs(e, e->segm_g, e->segm_n, e->k.seg_cap, nullptr, flags, 0, all ? roll->obs : nullptr, mode == MODE_STEP);
     r.seg_row0 = all ? 0 : nsteps - 1;
     r.obs_row_stride = all ? (long long)N * (long long)e->obs_bytes : 0;
     const int rows = all ? nsteps : 1;
@@ -2630,7 +2719,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       HIP_TRY(hipEventRecord(e->ev[2][slot], main));
       e->prof_n++;
     }
-    return TC_OK;
+    return noise_advance(e, mode, true, nsteps, stream);
   }
   if (do_raster && e->fuse && parts == 1 && kv != 13) {  // one launch: simulate + raster by the same wavefront
     // (the register-hungry K = 13 simulate stage spills when fused, so it stays two launches)
@@ -2638,7 +2727,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     fused_kern_t fk = kv == 5 ? pick_fused<5>(thick, cls) : kv == 8 ? pick_fused<8>(thick, cls) : pick_fused<9>(thick, cls);
     KArgs k = e->k;
     k.env0 = 0;
-    RArgs r = make_rargs(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, nullptr, flags, 0);
+    RArgs r = make_rargs(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, nullptr, flags, 0, nullptr, mode == MODE_STEP);
     const int lds = e->k.lds.total;  // covers both stages and the parked state
     StepArgs sa;
     memset(&sa, 0, sizeof(sa));
@@ -2659,8 +2748,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       HIP_TRY(hipEventRecord(e->ev[2][slot], main));
       e->prof_n++;
     }
-    if (e->noise_blobs > 0 && mode == MODE_STEP) return launch_noise(e, nullptr, stream, roll ? roll->obs : nullptr);
-    return TC_OK;
+    return noise_advance(e, mode, true, nsteps, stream);
   }
   for (int p = 0; p < parts; p++) {
     const int env0 = (int)((long long)N * p / parts), env1 = (int)((long long)N * (p + 1) / parts);
@@ -2685,7 +2773,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
     if (do_raster) {
       int rc = launch_raster(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, mode == MODE_RESET ? mask : nullptr, flags, st, env0,
-                             env1 - env0, roll ? roll->obs : nullptr);
+                             env1 - env0, roll ? roll->obs : nullptr, mode == MODE_STEP);
       if (rc != TC_OK) return rc;
     }
     if (p > 0) HIP_TRY(hipEventRecord(e->join_ev[p], st));
@@ -2695,8 +2783,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     HIP_TRY(hipEventRecord(e->ev[2][slot], main));
     e->prof_n++;
   }
-  if (do_raster && e->noise_blobs > 0 && mode == MODE_STEP) return launch_noise(e, nullptr, stream, roll ? roll->obs : nullptr);
-  return TC_OK;
+  return noise_advance(e, mode, do_raster, nsteps, stream);
 }
 
 extern "C" int tc_reset(tc_env* e, const int32_t* spawn_nodes, const uint8_t* mask, uint32_t flags, void* stream) {
@@ -2718,28 +2805,8 @@ extern "C" int tc_step_multi(tc_env* e, const void* car_control, int32_t control
     return TC_E_UNBOUND;
   }
   const bool want_obs = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && (e->k.b.obs || (rollout && rollout->obs));
-  // all steps in one simulate launch (+ one raster launch over the frames, or fused into it: see launch()); only the
-  // stand-alone noise pass still needs one pair of launches per step
-  const bool one_launch = want_obs ? e->noise_blobs == 0 : true;
-  if (one_launch) return launch(e, MODE_STEP, car_control, control_dtype, maneuver, nullptr, nullptr, flags, stream, n_steps, rollout);
-  // (noise pass): one step per group of launches, rollout rows advanced on the host
-  const size_t N = (size_t)e->k.N, esz = control_dtype == TC_F32 ? 4 : 8;
-  for (int k = 0; k < n_steps; k++) {
-    tc_rollout r;
-    memset(&r, 0, sizeof(r));
-    if (rollout) {
-      r.obs = rollout->obs ? rollout->obs + (size_t)k * N * (size_t)e->obs_bytes : nullptr;
-      r.reward = rollout->reward ? rollout->reward + k * N : nullptr;
-      r.terminated = rollout->terminated ? rollout->terminated + k * N : nullptr;
-      r.truncated = rollout->truncated ? rollout->truncated + k * N : nullptr;
-      r.cte = rollout->cte ? rollout->cte + k * N : nullptr;
-      r.heading_error = rollout->heading_error ? rollout->heading_error + k * N : nullptr;
-    }
-    int rc = launch(e, MODE_STEP, (const char*)car_control + (size_t)k * N * 2 * esz, control_dtype, maneuver + k * N, nullptr,
-                    nullptr, flags, stream, 1, rollout ? &r : nullptr);
-    if (rc != TC_OK) return rc;
-  }
-  return TC_OK;
+  (void)want_obs;
+  return launch(e, MODE_STEP, car_control, control_dtype, maneuver, nullptr, nullptr, flags, stream, n_steps, rollout);
 }
 
 extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar, char* name,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Step time of BASELINE config 3 (4096 envs, simple_layout, 64x64 classes, autoreset) with the 7-wrapper stack "A"
 of tests/golden/wrappers.json: none / fused into the step kernel / torch-side, and with NoiseObservationWrapper
-(its own kernel after each step).  Prints one JSON line.
+(fused into the raster stage), each as one launch per step and -- "_k32" -- as 32-step launches.  Prints one JSON line.
 Usage: python tools/bench_wrappers.py [--envs 4096] [--steps 300]"""
 import argparse
 import copy
@@ -78,6 +78,24 @@ def main():
             torch.cuda.synchronize()
             res["none_via_step"] = {"us_per_step": round((time.perf_counter() - t0) / a.steps * 1e6, 2)}
             e2.close()
+        if mode in ("none", "fused", "noise"):  # the same through K-step launches (tc_step_multi, rollout rows for every step)
+            K = 32
+            g2 = torch.Generator(device="cuda:0").manual_seed(1)
+            ccK = torch.stack([torch.rand((K, N), device="cuda:0", generator=g2) * 0.7 + 0.3,
+                               torch.rand((K, N), device="cuda:0", generator=g2) * 2 - 1], dim=2).float().contiguous()
+            mnK = torch.randint(0, 4, (K, N), device="cuda:0", generator=g2, dtype=torch.int32)
+            roll = env.alloc_rollout(K, keys=("obs", "reward", "terminated", "truncated"))
+            for _ in range(3):
+                env.step_multi(ccK, mnK, rollout=roll)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = max(1, a.steps // K)
+            for _ in range(reps):
+                env.step_multi(ccK, mnK, rollout=roll)
+            torch.cuda.synchronize()
+            dtk = (time.perf_counter() - t0) / (reps * K)
+            res[mode + "_k32"] = {"us_per_step": round(dtk * 1e6, 2), "env_steps_per_s": round(N / dtk)}
+            del roll
         env.close()
     print(json.dumps({"envs": N, "steps": a.steps, "stack": [c for c, _ in spec], **res}))
 
