@@ -133,6 +133,32 @@ def test_autoreset_consumes_spawn_queue():
     assert int(vec.state["lp_len"][0]) == 4
 
 
+def test_top_up_spawn_queue_continues_each_envs_seeded_stream():
+    """an env forced to re-spawn 10 times through a queue of 4, topped up in between, sees exactly the spawn nodes that
+    ONE generator seeded like the reference env (seed + i) draws in a row (map.py:51-69) -- no replay, no skipped draw"""
+    from tinycarlo_amd import gym as tgym
+    cfg = cfg_for("simple_layout", "r64")
+    vec = OracleVecEnv(cfg, num_envs=3, autoreset=True, spawn_queue_len=4)
+    vec.no_observation = True
+    vec.reset(seed=40)
+    want = []
+    for i in range(3):
+        r = tgym.np_random(40 + i)[0]
+        want.append([vec.map.sample_spawn_node(r) for _ in range(12)])   # [0] is the reset() draw itself
+    seen = [[] for _ in range(3)]
+    cc = np.tile(np.array([[0.5, 0.0]]), (3, 1))
+    for t in range(10):
+        vec._aux["needs_reset"][:] = torch.tensor([1, 1 if t % 2 == 0 else 0, 0], dtype=torch.uint8)
+        vec.step({"car_control": cc, "maneuver": np.zeros(3, dtype=np.int32)})
+        for i in range(3):
+            if (i == 0) or (i == 1 and t % 2 == 0):
+                seen[i].append(int(vec.state["local_path"][i, 0]))
+        if t % 3 == 2:
+            assert vec.top_up_spawn_queue() >= 1       # before env 0 uses up its 4 entries
+    assert seen[0] == want[0][1:11] and seen[1] == want[1][1:6] and seen[2] == []
+    assert int((vec.out["status"] & 16).sum()) == 0    # TC_S_SPAWN_WRAPPED never raised
+
+
 def test_no_observation_and_render():
     cfg = cfg_for("simple_layout", "r64", "classes")
     env = TinyCarloEnv(config=cfg, render_mode="rgb_array")

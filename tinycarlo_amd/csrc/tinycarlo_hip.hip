@@ -1088,7 +1088,19 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
             const int* sg = segg + 5 * (base + tid);
             long long qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3;
             TSTAMP(20);
-            if (!(a.flags & DBG_SKIP_QUAD) && r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
+            // Frames taller than one LDS band are rasterised band by band, and every band runs this set-up again.  A
+            // segment whose rows cannot reach the band is dropped before any of it: ThickLine paints within
+            // thickness / 2 + 1 rows of the segment (quad corners p +- dp with |dp| <= thickness / 2 + 1 px, cap radius
+            // (thickness + 1) / 2), and `thickness + 2` rows are allowed here.  On cfg5 (12 bands) a segment survives
+            // this in 1-3 bands instead of 12.
+            bool touch = true;
+            if (cam.n_bands > 1) {
+              const long long ya = sg[2], yb = sg[4], mg = (long long)cam.thickness + 2;
+              const long long ymin = (ya < yb ? ya : yb) - mg, ymax = (ya < yb ? yb : ya) + mg;
+              touch = ymax >= y0 && ymin < y1;
+            }
+            if (touch && !(a.flags & DBG_SKIP_QUAD) &&
+                r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
               TSTAMP(21);
               okq = 1;
               dpx = (int)(qx0 - (long long)sg[1] * TC_XY_ONE);
@@ -1194,6 +1206,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
           const int* sg = segg + 5 * k;
           r.bits = bits + sg[0] * plane;
           const int cx = (t & 1) ? sg[3] : sg[1], cy = (t & 1) ? sg[4] : sg[2];
+          if (cam.n_bands > 1 && ((long long)cy + cam.cap_r < y0 || (long long)cy - cam.cap_r >= y1)) continue;  // cap outside the band
           if (cam.cap_r < 32)
             r_cap(r, cx, cy, cam.cap_r, cam.cap_hw);
           else

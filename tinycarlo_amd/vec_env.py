@@ -365,6 +365,34 @@ class TinyCarloVecEnv(gym.Env):
         self._aux["spawn_queue"].copy_(torch.from_numpy(q))
         self._aux["spawn_cursor"].zero_()
 
+    def top_up_spawn_queue(self) -> int:
+        """spawn="host": continues every env's seeded spawn stream past the entries the kernel has consumed.
+
+        The queue holds `spawn_queue_len` pre-drawn spawn nodes per env and the kernel reads it cyclically, so an env
+        that re-spawned more often than that would replay nodes (flagged TC_S_SPAWN_WRAPPED in `status`).  This keeps
+        the entries an env has not used yet, appends as many fresh draws from that env's numpy generator as it has
+        used, and clears the cursors -- the sequence of spawn nodes each env sees stays exactly the one the reference
+        env seeded `seed + i` would draw, for as long as this is called before any env uses up its queue (call it
+        between rollouts: one device->host copy of the cursors, host work only for envs that re-spawned).
+        Returns the largest number of entries any env had consumed."""
+        if not self.autoreset or self.spawn != "host":
+            return 0
+        cur = self._aux["spawn_cursor"].cpu().numpy()
+        used = int(cur.max()) if cur.size else 0
+        if used == 0:
+            return 0
+        q = self._aux["spawn_queue"].cpu().numpy()
+        L_ = self.spawn_queue_len
+        for i in np.flatnonzero(cur > 0):
+            c = int(min(cur[i], L_))
+            fresh = [self.map.sample_spawn_node(self._rngs[i]) for _ in range(c)]
+            pos = int(cur[i]) % L_ if cur[i] >= L_ else c      # a wrapped env restarts from what the kernel would read next
+            rest = np.concatenate([q[i, pos:], q[i, :pos]])[: L_ - c] if cur[i] >= L_ else q[i, c:]
+            q[i] = np.concatenate([rest, np.asarray(fresh, dtype=np.int32)])[:L_]
+        self._aux["spawn_queue"].copy_(torch.from_numpy(q))
+        self._aux["spawn_cursor"].zero_()
+        return used
+
     # ------------------------------------------------------------------ gym API
     def reset(self, seed: Optional[int] = None, options: Optional[Any] = None, mask=None):
         """env.py:101-113 for every env (or the envs selected by the boolean `mask`)."""
