@@ -8,7 +8,8 @@
 A "step" is one batched step() of `--envs` envs per GPU (default 4096): kinematics -> lanepath tracking -> lane-line
 distances -> camera clip/project -> raster -> uint8 observation store, inputs (actions) already resident in HBM,
 observations left in HBM.  The K timed steps are issued `--steps-per-launch` at a time through tc_step_multi (one
-wavefront stays with its env for all steps of a launch; default 32, `config.steps_per_launch`); every step's
+simulate launch covers a chunk of steps, one launch of steps x N workgroups draws their frames, chunks pipelined
+inside the call; default 128 steps per call, `config.steps_per_launch`); every step's
 observation is stored to its own row of a [steps_per_launch, N, ...] rollout buffer, so the bytes written per step
 are the same as with one launch per step (`--steps-per-launch 0` times that form, tc_step).
 Workloads (BASELINE.json configs):
@@ -70,20 +71,25 @@ def gen_actions(n_envs, n_steps, seed, device):
     return cc, man
 
 
-def pmc_traffic(workload, kernel, steps_per_launch):
-    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC summary of this command
+def pmc_traffic(workload, kernel, rows_per_dispatch):
+    """HBM bytes per dispatch of `kernel` from the COMMITTED rocprofv3 PMC summary of this command
     (profiles/<round>/<workload>_pmc.json: separate --pmc FETCH_SIZE and WRITE_SIZE passes; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950), or None when no summary of the same launch shape is committed.
-    It is a profile of an earlier run of this command, not a measurement of this run: `traffic_source` says so."""
+    MI355X_MICROARCH.md prescribes for gfx950), or None when none is committed.  The summary holds per-dispatch means
+    of dispatches that cover `_rows_per_dispatch` steps each; one workgroup handles one (step, env) and touches only its
+    own bytes, so a dispatch of a different number of steps is priced pro rata and `traffic_source` says so.
+    It is a profile of an earlier run of this command, not a measurement of this run."""
     path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"{workload}_pmc.json")
     try:
         with open(path) as f:
             j = json.load(f)
-        if int(j.get("_steps_per_launch", -1)) != int(steps_per_launch):
-            return None, None
+        rows = float(j["_rows_per_dispatch"])
         b = sum((2 * j[k]["FETCH_SIZE"] + j[k]["WRITE_SIZE"]) * 1024.0 for k in kernel.split("+"))
-        return b, f"profiles/{PROFILE_ROUND}/{workload}_pmc.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
-                  f"2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction; build {j.get('_build', '?')})"
+        src = (f"profiles/{PROFILE_ROUND}/{workload}_pmc.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+               f"this command, 2*FETCH_SIZE + WRITE_SIZE per dispatch of {rows:g} steps, gfx950 correction; build {j.get('_build', '?')})")
+        if abs(rows - rows_per_dispatch) > 1e-9:
+            b *= rows_per_dispatch / rows
+            src += f"; scaled x{rows_per_dispatch / rows:.4g} to this run's {rows_per_dispatch:g} steps per dispatch"
+        return b, src
     except Exception:
         return None, None
 
@@ -154,8 +160,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the workload's)")
     ap.add_argument("--steps-per-launch", type=int, default=None,
-                    help="steps issued per kernel launch through tc_step_multi (default 32; cfg5: 2 -- its rollout rows are "
-                         "7.5 GB each); 0 = one tc_step launch per step")
+                    help="steps issued per tc_step_multi call (default 128; cfg5: 2 -- its rollout rows are 7.5 GB each); "
+                         "0 = one tc_step launch per step")
     ap.add_argument("--preroll-ms", type=float, default=300.0,
                     help="untimed steps issued for about this long before the warm-up so that a short run is measured at "
                          "steady clocks (reported as config.preroll_steps)")
@@ -200,7 +206,9 @@ def main():
     assert hi - lo == n
     M = args.steps_per_launch
     if M is None:
-        M = 2 if args.workload == "cfg5" else 32
+        # 128 steps per call: the library pipelines such a call internally (simulate launch of chunk c+1 beside the frame
+        # launch of chunk c, 16 steps per chunk), which needs several chunks to pay; cfg5's rollout rows are 7.5 GB each
+        M = 2 if args.workload == "cfg5" else 128
     env = TinyCarloVecEnv(cfg, num_envs=n, device=device, autoreset=True, spawn_queue_len=64)
     env.no_observation = w["no_obs"]
     env.reset(seed=shard_seed(0, rank, n))  # env i of rank r is the reference env seeded r*n + i
@@ -325,24 +333,33 @@ def main():
     info = env.launch_info(max(M, 1))  # what the library really launches (not guessed from timings)
     kname = info["kernel"]
     fused = info["fused"]
-    spl = M if M >= 1 else 1                       # steps per launch of the dominant kernel
-    full_launches = (K // M) if M >= 1 else K      # the sampled means below include a short last launch if K % M != 0
-    steps_in_sampled = K / max(n_l, 1)             # mean steps per launch over the timed region
-    two = "+" in kname                             # simulate launch + frame (or raster) launch
+    full_launches = (K // M) if M >= 1 else K      # the sampled means below include a short last call if K % M != 0
+    steps_in_sampled = K / max(n_l, 1)             # mean steps per call over the timed region
+    # A K-step call that stores every frame is issued as pipelined chunks (include/tinycarlo_hip.h, tc_step_multi): the
+    # library reports how many steps one kernel DISPATCH covers, and the roofline below is per dispatch, the unit
+    # rocprofv3's kernel trace and PMC counters are in.
+    spd = max(1, min(info.get("steps_per_dispatch", 1), max(M, 1)))
+    n_disp = -(-int(round(steps_in_sampled)) // spd) if M >= 1 else 1
+    rows_per_dispatch = steps_in_sampled / n_disp
+    two = "+" in kname                             # simulate dispatches + frame (or raster) dispatches
     if two:
         # The dominant kernel is the one that writes the observations (tc_frame_kernel: camera + raster of one frame per
         # workgroup).  Its algorithmic bytes per frame: the observation, written once, plus the 32-byte pose row it
-        # reads; the 240 B of state / action / info traffic belong to the simulate launch in front of it.
+        # reads; the 240 B of state / action / info traffic belong to the simulate dispatch in front of it.
+        # HIP events bracket the call's first..last frame dispatch on the stream they run on; the dispatches follow
+        # each other without a gap there (simulating a chunk is faster than drawing it), so span / dispatches is the
+        # average dispatch duration -- the figure rocprofv3's kernel stats give for the same command.
         dom = kname.split("+")[-1]
-        kernel_s = prof["raster_us"] * 1e-6        # per LAUNCH (HIP events around that kernel on the launch stream)
+        kernel_s = prof["raster_us"] * 1e-6 / n_disp
+        sim_s = prof["simulate_us"] * 1e-6 / n_disp
         dom_bytes_per_frame = b_obs + 32
     else:
         dom = kname
-        kernel_s = prof["simulate_us"] * 1e-6
+        kernel_s = sim_s = prof["simulate_us"] * 1e-6 / n_disp
         dom_bytes_per_frame = bytes_per_env_step
-    kbytes = dom_bytes_per_frame * n * steps_in_sampled
+    kbytes = dom_bytes_per_frame * n * rows_per_dispatch
     achieved = kbytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(args.workload, dom, spl) if n == WORKLOADS[args.workload]["envs"] else (None, None)
+    traffic, traffic_src = pmc_traffic(args.workload, dom, rows_per_dispatch) if n == WORKLOADS[args.workload]["envs"] else (None, None)
     out = {
         "metric": "env-steps/sec (whole node)",
         "value": world * n * K / dt,
@@ -370,13 +387,14 @@ def main():
                    "lds_bytes_per_env": env.lds_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": dom, "kernel_us": kernel_s * 1e6, "steps_per_launch": steps_in_sampled,
-                     "kernel_us_per_step": kernel_s * 1e6 / steps_in_sampled if steps_in_sampled else None,
+                     "kernel": dom, "kernel_us": kernel_s * 1e6, "steps_per_dispatch": rows_per_dispatch,
+                     "dispatches_per_call": n_disp, "steps_per_call": steps_in_sampled,
+                     "kernel_us_per_step": kernel_s * 1e6 / rows_per_dispatch,
                      "algorithmic_bytes_per_launch": kbytes, "algorithmic_bytes_per_unit": dom_bytes_per_frame,
                      "algorithmic_bytes_per_env_step": bytes_per_env_step,
                      "launches_per_call": kname,
-                     "kernels_us": ({kname: prof["simulate_us"]} if not two else
-                                    {kname.split("+")[0]: prof["simulate_us"], dom: prof["raster_us"]}),
+                     "kernels_us": ({kname: sim_s * 1e6} if not two else
+                                    {kname.split("+")[0]: sim_s * 1e6, dom: kernel_s * 1e6}),
                      "event_samples": prof["launches"], "full_launches": full_launches,
                      # the whole step (all launches, gaps included) against SURVEY 8d's bytes per env-step
                      "step_us": step_s * 1e6, "step_achieved_GBs": bytes_per_env_step * n / step_s / 1e9,

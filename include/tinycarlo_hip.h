@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 3
+#define TC_ABI_VERSION 4
 #define TC_MAX_LAYERS 16
 
 /* error codes */
@@ -241,10 +241,14 @@ int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const i
  *   rollout (may be NULL): per-step copies of the outputs a learner reads, each [K][N] (obs: [K][N][obs_bytes]) or
  *   NULL.  With rollout->obs the observation of step k goes to rollout->obs[k] and the bound obs buffer is left
  *   untouched; without it every step stores its observation into the bound buffer (which ends up holding the last).
- * Launches: ONE simulate launch that loops over the K steps (one wavefront per env) and, when observations are
- * rendered, ONE raster launch of K x N workgroups over the frames (without rollout->obs only the last step's frame is
- * drawn: the others would be overwritten); env var TC_MULTI_SPLIT=0 selects a single fused launch instead, in which the
- * same wavefront also rasterises each of its env's frames. */
+ * Launches: a simulate launch that loops over the steps and, when observations are rendered, a launch of steps x N
+ * workgroups over the frames (camera + raster of one frame each; without rollout->obs only the last step's frame is
+ * drawn: the others would be overwritten).  With rollout->obs the call is issued in chunks of 16 steps (a quarter of
+ * the call if that is less): the frames of chunk c are produced on an internal stream while chunk c+1 is simulated on
+ * the caller's, and the internal stream is joined back before the call's work on the caller's stream ends, so
+ * everything still completes in stream order.  Env vars: TC_CHUNK=0 no pipelining, TC_ENV_GROUPED=0 one wavefront per
+ * env in the simulate launch, TC_MULTI_SPLIT=0 a single fused launch in which the same wavefront simulates its env and
+ * rasterises each of its frames. */
 typedef struct {
   uint8_t* obs;          /* [K][N][tc_env_obs_bytes] */
   double* reward;        /* [K][N] */
@@ -258,10 +262,12 @@ int tc_step_multi(tc_env* env, const void* car_control, int32_t control_dtype, c
 
 /* What the library launches for a call of n_steps steps (1 = tc_step) with the current settings -- for benchmark
  * labels, not for control flow: fused = 1 when simulate + raster run as one kernel; kvar = register-cache variant of
- * the simulate stage (5, 8, 9, 13); name receives the kernel symbol prefix ("tc_step_kernel",
- * "tc_env_kernel+tc_raster_kernel" or "tc_env_kernel"), at most name_cap bytes including the terminator. */
-int tc_env_launch_info(const tc_env* env, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar, char* name,
-                       int32_t name_cap);
+ * the simulate stage (5, 8, 9, 13); steps_per_dispatch = steps one kernel dispatch of the call covers when every
+ * step's frame goes to a rollout (a K-step call is issued as pipelined chunks: see tc_step_multi); name receives the
+ * kernel symbols ("tc_step_kernel", "tc_envg_kernel+tc_frame_kernel", "tc_env_kernel+tc_raster_kernel", "tc_env_kernel"),
+ * at most name_cap bytes including the terminator. */
+int tc_env_launch_info(const tc_env* env, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar,
+                       int32_t* steps_per_dispatch, char* name, int32_t name_cap);
 
 /* Renderer.render_camera_frame_{rgb,classes} alone (renderer.py:36-51): rasterise caller-provided segment lists
  * into the bound observation tensor.  segments: device int32 [N][capacity][5] rows of (layer, x0, y0, x1, y1) --

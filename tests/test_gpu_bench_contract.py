@@ -31,18 +31,22 @@ def test_default_workload_line():
     assert d["value"] > 5e6                                  # the north star's target is 1e6 on this configuration
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    # K-step calls: one simulate launch + one launch over the frames; the roofline kernel is the one writing the frames
-    assert r["launches_per_call"] == "tc_env_kernel+tc_frame_kernel" and r["kernel"] == "tc_frame_kernel"
-    assert set(r["kernels_us"]) == {"tc_env_kernel", "tc_frame_kernel"} and all(v > 0 for v in r["kernels_us"].values())
+    # K-step calls: simulate launches + launches over the frames; the roofline kernel is the one writing the frames
+    assert r["launches_per_call"] == "tc_envg_kernel+tc_frame_kernel" and r["kernel"] == "tc_frame_kernel"
+    assert set(r["kernels_us"]) == {"tc_envg_kernel", "tc_frame_kernel"} and all(v > 0 for v in r["kernels_us"].values())
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     assert r["algorithmic_bytes_per_env_step"] == 240 + 5 * 64 * 64
-    # 40 steps at (up to) 32 per launch = 2 launches of 20 steps through tc_step_multi
-    assert d["config"]["entry_point"] == "tc_step_multi" and d["config"]["launches_timed"] == 2 and r["steps_per_launch"] == 20
+    # 40 steps at up to 128 per call = ONE tc_step_multi call of 40 steps, pipelined inside as 4 chunks of 10; the
+    # roofline is per kernel dispatch (rocprofv3's unit), i.e. per chunk
+    assert d["config"]["entry_point"] == "tc_step_multi" and d["config"]["launches_timed"] == 1 and r["steps_per_call"] == 40
+    assert r["steps_per_dispatch"] == 10 and r["dispatches_per_call"] == 4
     assert r["algorithmic_bytes_per_unit"] == 5 * 64 * 64 + 32     # a frame: the observation + the pose row it is drawn from
-    assert r["algorithmic_bytes_per_launch"] == 20 * 4096 * (5 * 64 * 64 + 32)
-    assert abs(r["kernel_us_per_step"] * 20 - r["kernel_us"]) < 1e-6 * r["kernel_us"]
+    assert r["algorithmic_bytes_per_launch"] == 10 * 4096 * (5 * 64 * 64 + 32)
+    assert abs(r["kernel_us_per_step"] * 10 - r["kernel_us"]) < 1e-6 * r["kernel_us"]
+    assert abs(r["kernels_us"]["tc_frame_kernel"] - r["kernel_us"]) < 1e-9
     assert abs(r["step_frac"] - (240 + 5 * 64 * 64) * 4096 / (r["step_us"] * 1e-6) / 8e12) < 1e-9
-    assert r["traffic"] is None or r["traffic"] > 0.9 * r["algorithmic_bytes_per_launch"]
+    # HBM traffic of that dispatch (committed PMC summary, scaled to 10 steps): at least the bytes it must write
+    assert r["traffic"] is None or 0.9 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 3 * r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and "oracle" in c["sample"]
     assert c["one_thread"]["cores"] == 1 and 0 < c["one_thread"]["value"] <= c["value"] * 1.5   # 1 thread and all cores
@@ -51,12 +55,13 @@ def test_default_workload_line():
 def test_other_workloads_and_flags():
     d = _run("--workload", "cfg2", "--steps", "20", "--warmup", "4", "--no-cpu-baseline")
     assert "cpu_baseline" not in d and d["roofline"]["kernel"] == "tc_env_kernel"
-    assert d["roofline"]["algorithmic_bytes_per_launch"] == 20 * 4096 * 240
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 20 * 4096 * 240 and d["roofline"]["dispatches_per_call"] == 1
     d = _run("--workload", "cfg4", "--envs", "256", "--steps", "10", "--warmup", "2", "--no-cpu-baseline")
     assert d["config"]["envs_per_gpu"] == 256 and d["roofline"]["traffic"] is None     # PMC summary is for the full size only
     assert d["roofline"]["kernel"] == "tc_frame_kernel"    # knuffingen: the K = 9 variant, two camera layer groups
-    assert d["roofline"]["algorithmic_bytes_per_launch"] == 10 * 256 * (5 * 128 * 128 + 32)
+    assert d["roofline"]["dispatches_per_call"] == 4       # 10 steps: chunks of 3, 3, 3, 1
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 2.5 * 256 * (5 * 128 * 128 + 32)
     # the single-step entry point stays measurable: one tc_step launch per step
     d = _run("--steps", "16", "--warmup", "4", "--steps-per-launch", "0", "--no-cpu-baseline")
-    assert d["config"]["entry_point"] == "tc_step" and d["roofline"]["steps_per_launch"] == 1
+    assert d["config"]["entry_point"] == "tc_step" and d["roofline"]["steps_per_dispatch"] == 1
     assert d["roofline"]["kernel"] == "tc_step_kernel" and d["roofline"]["algorithmic_bytes_per_launch"] == 4096 * (240 + 5 * 64 * 64)

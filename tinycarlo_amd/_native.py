@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TINYCARLO_HIP_LIB: load another build of the same library (tools/phase_clock.py uses the instrumented one)
 LIB_PATH = os.environ.get("TINYCARLO_HIP_LIB") or os.path.join(_HERE, "libtinycarlo_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_TERMS, MAX_LAYERS = 8, 16
 FMT_RGB, FMT_CLASSES = 0, 1
 F32, F64 = 0, 1
@@ -127,7 +127,7 @@ def lib():
     L.tc_step_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint32,
                                 C.POINTER(Rollout), C.c_void_p]
     L.tc_env_launch_info.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                     C.c_char_p, C.c_int32]
+                                     C.POINTER(C.c_int32), C.c_char_p, C.c_int32]
     L.tc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.tc_render_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     if L.tc_abi_version() != ABI_VERSION:

@@ -43,6 +43,8 @@ struct DevMap {
   const int* edge_layer;  // layer of each edge
   const double* ori_fwd;  // per lane-line edge: atan2(evy, evx)
   const double* ori_rev;  // per lane-line edge: atan2(-evy, -evx)
+  const double4* edge_xy; // per lane-line edge: both end points (n0.x, n0.y, n1.x, n1.y) in one 32-byte record, so that a
+                          // scan over edges is one independent load per edge instead of edge -> two dependent node loads
   unsigned char colors[16][3];
   int lpN, lpE;
   int first_spawnable;    // a lanepath node with an out-edge (fallback for invalid spawn requests)
@@ -303,6 +305,41 @@ __device__ inline int d_nearest_edge_with_orientation(const DevMap& m, double px
   return best;
 }
 
+// lowest-index argmin among the EL lanes of an aligned lane group (EL a power of two < 64): xor butterfly, after which
+// every lane of the group holds the result.  All lanes of a group must be active (group-uniform control flow).
+template <int EL>
+__device__ __forceinline__ void group_argmin(double& v, int& idx) {
+#pragma unroll
+  for (int off = EL / 2; off > 0; off >>= 1) {
+    const double ov = __shfl_xor(v, off);
+    const int oi = __shfl_xor(idx, off);
+    const bool take = (oi >= 0) && (idx < 0 || ov < v || (ov == v && oi < idx));
+    v = take ? ov : v;
+    idx = take ? oi : idx;
+  }
+}
+
+// layer.py:59-74 over the lanepath by the EL lanes of one env's group (sub = lane within the group)
+template <int EL>
+__device__ inline int d_nearest_edge_with_orientation_g(const DevMap& m, double px, double py, double orientation,
+                                                        double margin_deg, const int sub) {
+  double lim = d_radians(margin_deg);
+  int best = -1;
+  double bd = 0;
+  for (int e = sub; e < m.lpE; e += EL) {
+    if (!(tc_fabs(d_clip_angle(m.lp_ori[e] - orientation)) <= lim)) continue;
+    int2 ed = m.lp_edges[e];
+    double2 a = m.lp_nodes[ed.x], b = m.lp_nodes[ed.y];
+    double d = tc_fabs(d_dist(px, py, a.x, a.y) + d_dist(px, py, b.x, b.y));
+    if (best < 0 || d < bd) {
+      best = e;
+      bd = d;
+    }
+  }
+  group_argmin<EL>(bd, best);
+  return best;
+}
+
 // ------------------------------------------------------------------ car.py
 __device__ inline void d_update_front(const DevCar& c, CarState& s) {  // car.py:167-168
   s.cth = tc_cos(s.theta);
@@ -336,7 +373,9 @@ struct PathInfo {
   int valid;              // 0: local_path was left untouched (early truncation) -> read it from the tables
 };
 
-// car.py:127-148
+// car.py:127-148.  EL = lanes that work on this env together: 64 (one wavefront per env, tid = lane) or a lane group
+// of the grouped simulate kernel (tid = lane within the group); it only matters for the U-turn search.
+template <int EL = 64>
 __device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuver, int& status, PathInfo& pi, const int tid) {
   double fx = s.front_x, fy = s.front_y;
   int e0 = s.lp[0], e1 = s.lp[1];
@@ -344,7 +383,8 @@ __device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuv
   double mdir = d_clip_angle(d_edge_ori_f(m, N0, e0, e1) + (maneuver * TC_PI) / 2);
   int ne0, ne1;
   if (maneuver == 2 && s.last_maneuver != 2) {  // wave-uniform branch
-    int e = d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0, tid);
+    int e = EL == 64 ? d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0, tid)
+                     : d_nearest_edge_with_orientation_g<(EL == 64 ? 32 : EL)>(m, fx, fy, mdir, 30.0, tid);
     mdir = d_clip_angle(mdir + TC_PI);
     if (e < 0) {
       status |= 1;  // TC_S_UTURN_NO_EDGE

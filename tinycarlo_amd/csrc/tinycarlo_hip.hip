@@ -253,6 +253,48 @@ __device__ __forceinline__ void d_apply_terms(const tc_term* terms, int n_terms,
   }
 }
 
+// The same stack for the grouped simulate kernel, where every lane of an env's group runs it: distances and counters
+// of the env sit in a small LDS record (all lanes of the group read and write the same words with the same values).
+__device__ __forceinline__ void d_apply_terms_mem(const tc_term* terms, int n_terms, int* cnt, double tw, int C, double cte,
+                                                  double vel, const double* dist, double& reward, int& terminated) {
+  const double half = tw / 2;
+  for (int t = 0; t < n_terms; t++) {
+    const tc_term* T = terms + t;
+    const int kind = T->kind;
+    const unsigned mask = T->layer_mask;
+    if (kind == TC_T_LANELINE_SPARSE_REWARD) {  // reward.py:20-21, utils.py:15-19
+      double local = 0.0;
+      for (int l = 0; l < C; l++)
+        if (((mask >> l) & 1u) && dist[l] < half) local += T->per_layer[l];
+      reward = reward + local;
+    } else if (kind == TC_T_LANELINE_LINEAR_REWARD) {  // reward.py:40-41
+      for (int l = 0; l < C; l++) reward = reward + d_linear_reward(dist[l], tw, T->per_layer[l], 0.0);
+    } else if (kind == TC_T_CTE_SPARSE_REWARD) {  // reward.py:60
+      double local = 0.0;
+      if (tc_fabs(cte) <= T->p[0]) local += T->p[1];
+      reward = reward + local;
+    } else if (kind == TC_T_CTE_LINEAR_REWARD) {  // reward.py:83
+      reward = reward + d_linear_reward(cte, T->p[0], T->p[1], T->p[2]);
+    } else if (kind == TC_T_LANELINE_CROSSING_TERMINATION) {  // termination.py:19-21
+      for (int l = 0; l < C; l++)
+        if (((mask >> l) & 1u) && dist[l] <= half) terminated = 1;
+    } else if (kind == TC_T_CTE_TERMINATION || kind == TC_T_CRASH_TERMINATION) {  // termination.py:39-47,61-69
+      const bool cond = kind == TC_T_CTE_TERMINATION ? (tc_fabs(cte) > T->p[0]) : (tc_fabs(vel) < T->p[0]);
+      int c = cnt[t];
+      if (cond) {
+        c += 1;
+        if (c >= T->number_of_steps) {
+          terminated = 1;
+          c = 0;
+        }
+      } else {
+        c = 0;
+      }
+      cnt[t] = c;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-lane register cache of the map: lane `tid` keeps nodes / edges (w*K + k)*64 + tid, k < K, of window w.
 // Maps up to 64*K nodes and edges (all bundled ones with K = 5 or 13) are a single window that is loaded once at
@@ -1690,6 +1732,230 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) vo
   if (s1.mode != MODE_RENDER) live_out(s1.a, smem, env);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Grouped simulate kernel for K-step calls: TC_EL lanes per env, 64 / TC_EL envs per wavefront.
+// Phases A and B of a step are ~900 + ~900 wave-instructions in the one-wavefront-per-env kernel above, and A is scalar
+// work that all 64 lanes repeat.  The chip is bound by vector issue (counters: the frame kernel keeps the VALUs 96 %
+// busy, the per-env simulate kernel 71 %), so what a step COSTS is its instruction count.  Here an instruction of phase
+// A serves 64 / TC_EL envs at once (control flow may differ between envs: plain SIMT divergence), and phase B gives each
+// lane of a group every TC_EL-th edge of a layer -- two distances per edge straight from the map (L1-resident), no
+// staging of node distances, an xor butterfly over the group for the argmin -- with the per-layer tail evaluated by
+// every lane of the group, so nothing has to be passed around afterwards.  State lives in registers for the whole
+// launch.  Per env-step: ~2 300 wave-instructions / 8 envs instead of ~1 700 / 1 env.
+// The price is latency (a group of 8 lanes walks 33 edges per layer pass one after the other), which nobody waits for:
+// the kernel leaves most of the chip's issue slots free for the frame kernel of the previous call.
+#define TC_EL 8
+struct GroupLds {  // per env of the wavefront: what the reward / termination terms read and count
+  double dist[TC_MAX_LAYERS];
+  int cnt[TC_MAX_TERMS];
+};
+
+__global__ __launch_bounds__(TC_NT) void tc_envg_kernel(StepArgs sa_unused) {
+  __shared__ GroupLds glds[TC_NT / TC_EL];
+  // Highest issue priority: when this kernel shares the chip with the frame kernel of the previous chunk it is the
+  // critical path (a serial chain per step, few instructions), and the frame wavefronts would otherwise crowd it out
+  // of the vector issue slots by sheer number (measured: 36 us per step beside them, 21 us alone).
+  __builtin_amdgcn_s_setprio(3);
+  const StepArgs& s0 = step_args();
+  const int lane = threadIdx.x, sub = lane & (TC_EL - 1), grp = lane / TC_EL;
+  const int N = s0.a.N;
+  int env = s0.a.env0 + blockIdx.x * (TC_NT / TC_EL) + grp;
+  const bool live = env < N;  // groups past the last env compute on a copy of it and store nothing
+  env = live ? env : N - 1;
+  GroupLds& gl = glds[grp];
+  CarState s;
+  int nr = 0, cursor = 0, cursor0 = 0;
+  bool have_trig = false;
+  {
+    const tc_buffers& b = s0.a.b;
+    s.x = b.x[env];
+    s.y = b.y[env];
+    s.theta = b.theta[env];
+    s.velocity = b.velocity[env];
+    s.steering = b.steering[env];
+    s.radius = b.radius[env];
+    s.front_x = b.front_x[env];
+    s.front_y = b.front_y[env];
+    s.cth = s.sth = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.lp[i] = b.local_path[env * 8 + i];
+    s.lp_len = b.lp_len[env];
+    s.last_maneuver = b.last_maneuver[env];
+    if (s0.flags & TC_F_AUTORESET) {
+      nr = b.needs_reset[env];
+      cursor = cursor0 = b.spawn_cursor[env];
+    }
+    if (sub < TC_MAX_TERMS) gl.cnt[sub] = (s0.a.n_terms > 0 && s0.a.term_counters) ? s0.a.term_counters[(size_t)env * TC_MAX_TERMS + sub] : 0;
+    static_assert(TC_EL >= TC_MAX_TERMS, "one lane per term counter");
+  }
+  double cte = 0, he = 0, reward = 0;
+  int terminated = 0, trunc = 0, status = 0;
+  int my_ne = -1;       // lane sub < ... keeps nothing: nearest edges are kept per layer in registers of all lanes
+  (void)my_ne;
+  const int nsteps = s0.ma.nsteps;
+  for (int k = 0; k < nsteps; k++) {
+    const StepArgs& sa = step_args();  // re-read per step: see step_args()
+    const KArgs& a = sa.a;
+    const DevMap& m = a.m;
+    const tc_buffers& b = a.b;
+    const unsigned int flags = sa.flags;
+    const size_t row0 = (size_t)k * a.N;
+    const RollStep roll = roll_at(sa.ma.roll, row0);
+    status = 0;
+    trunc = 0;
+    PathInfo pinfo;
+    pinfo.ax = pinfo.ay = pinfo.bx = pinfo.by = pinfo.ori = 0;
+    pinfo.valid = 0;
+    bool fresh = false;
+    if ((flags & TC_F_AUTORESET) && nr) {
+      const int cur = cursor;
+      int node;
+      if ((flags & TC_F_DEVICE_SPAWN) && a.spawn_n > 0) {
+        node = a.spawn_tab[tc_spawn_index(a.spawn_seed, (uint32_t)env, (uint32_t)cur, (uint32_t)a.spawn_n)];
+      } else {
+        if ((unsigned)cur >= (unsigned)b.spawn_queue_len) status |= TC_S_SPAWN_WRAPPED;
+        node = b.spawn_queue[(size_t)env * b.spawn_queue_len + ((unsigned)cur % (unsigned)b.spawn_queue_len)];
+      }
+      d_reset(m, a.car, s, checked_spawn(m, node, status));
+      fresh = true;
+      have_trig = true;
+      cursor = cur + 1;
+    } else if ((unsigned)s.lp[0] >= (unsigned)m.lpN || (unsigned)s.lp[1] >= (unsigned)m.lpN) {
+      status |= TC_S_NOT_RESET;
+      trunc = 1;
+    } else {
+      double v, st;
+      if (sa.cdtype == TC_F32) {
+        const float* cc = (const float*)sa.car_control + row0 * 2;
+        v = (double)cc[2 * env];
+        st = (double)cc[2 * env + 1];
+      } else {
+        const double* cc = (const double*)sa.car_control + row0 * 2;
+        v = cc[2 * env];
+        st = cc[2 * env + 1];
+      }
+      v = d_np_clip(v, -1.0, 1.0);  // env.py:118
+      st = d_np_clip(st, -1.0, 1.0);
+      const int man = sa.maneuver[row0 + env];
+      d_car_kinematics(a.car, s, v, st, have_trig);
+      trunc = d_find_local_path<TC_EL>(m, s, man, status, pinfo, sub);
+      have_trig = true;
+    }
+    // ---- info (car.py:46-53), default reward / termination (env.py:93,99)
+    const bool have_info = !fresh && s.lp_len >= 2;
+    cte = 0;
+    he = 0;
+    if (have_info && !pinfo.valid) {  // path kept from an earlier step (truncated before it was rebuilt)
+      double2 n1 = m.lp_nodes[s.lp[2]], n2 = m.lp_nodes[s.lp[3]];
+      pinfo.ax = n1.x;
+      pinfo.ay = n1.y;
+      pinfo.bx = n2.x;
+      pinfo.by = n2.y;
+      pinfo.ori = d_lp_edge_ori(m, s.lp[2], s.lp[3]);
+    }
+    if (have_info) {
+      cte = d_distance_to_edge(pinfo.ax, pinfo.ay, pinfo.bx, pinfo.by, s.front_x, s.front_y);
+      he = d_clip_angle(pinfo.ori - s.theta);
+    }
+    reward = 0;
+    terminated = 0;
+    if (!(flags & TC_F_WRAPPED) && !fresh) {
+      double r = (-1 / a.car.track_width) * cte + 1;
+      reward = (0 > r) ? 0 : r;
+      terminated = cte > (a.car.track_width * 10);
+    }
+    // ---- phase B: nearest lane-line edge and distance per layer (car.py:55-64, layer.py:33-44,126-164)
+    const int C = m.C;
+    const bool last = k == nsteps - 1;
+    for (int l = 0; l < C; l++) {
+      double dist_l = 0;
+      int ne = -1;
+      if (have_info) {
+        const int eo = m.edge_off[l], eend = m.edge_off[l + 1];
+        double bd = 0;
+        int best = -1;
+#pragma unroll 4
+        for (int e = eo + sub; e < eend; e += TC_EL) {  // this lane's edges of the layer, ascending (layer.py:43)
+          const double4 q = m.edge_xy[e];  // both end points: independent loads, several in flight
+          const double d = tc_fabs(d_dist(s.x, s.y, q.x, q.y) + d_dist(s.x, s.y, q.z, q.w));
+          if (best < 0 || d < bd) {
+            best = e - eo;
+            bd = d;
+          }
+        }
+        group_argmin<TC_EL>(bd, best);
+        ne = best;
+        if (ne >= 0) {
+          const int ge = eo + ne;
+          const double4 q = m.edge_xy[ge];
+          const double2 n0 = make_double2(q.x, q.y), n1 = make_double2(q.z, q.w);
+          bool certain;
+          bool inb = d_within_bounds_filter(n0.x, n0.y, n1.x, n1.y, s.x, s.y, certain);
+          if (!certain) inb = d_within_bounds(n0.x, n0.y, n1.x, n1.y, m.ori_fwd[ge], m.ori_rev[ge], s.x, s.y);
+          if (inb) {
+            dist_l = tc_fabs(d_distance_to_edge(n0.x, n0.y, n1.x, n1.y, s.x, s.y));
+          } else {
+            const double da = d_dist(s.x, s.y, n0.x, n0.y);
+            const double db = d_dist(s.front_x, s.front_y, n1.x, n1.y);  // FRONT axle for n1 (car.py:64)
+            dist_l = db < da ? db : da;
+          }
+        }
+      }
+      gl.dist[l] = dist_l;  // (every lane of the group writes the same value)
+      if (last && live && sub == 0) {
+        b.laneline_distances[(size_t)env * C + l] = dist_l;
+        b.nearest_edge[(size_t)env * C + l] = ne;
+      }
+    }
+    // ---- reward / termination wrappers (a re-spawned env did not go through Wrapper.step)
+    if (a.n_terms > 0 && !fresh)
+      d_apply_terms_mem(a.terms, a.n_terms, gl.cnt, a.car.track_width, C, cte, have_info ? s.velocity : 0.0, gl.dist, reward,
+                        terminated);
+    nr = (flags & TC_F_AUTORESET) ? (terminated || trunc) : 0;
+    // ---- this step's rollout rows and pose row
+    if (live && sub == 0) {
+      if (roll.cte) roll.cte[env] = cte;
+      if (roll.heading_error) roll.heading_error[env] = he;
+      if (roll.truncated) roll.truncated[env] = (unsigned char)trunc;
+      if (roll.reward) roll.reward[env] = reward;
+      if (roll.terminated) roll.terminated[env] = (unsigned char)terminated;
+    }
+    if (sa.ma.pose_rows && live && sub < 4) {
+      double pv = s.x;
+      pv = sub == 1 ? s.y : pv;
+      pv = sub == 2 ? (have_trig ? s.cth : tc_cos(-s.theta)) : pv;
+      pv = sub == 3 ? (have_trig ? -s.sth : tc_sin(-s.theta)) : pv;
+      sa.ma.pose_rows[(row0 + env) * 4 + sub] = pv;
+    }
+  }
+  // ---- state and the last step's outputs back to the caller's buffers
+  const StepArgs& s1 = step_args();
+  const tc_buffers& b = s1.a.b;
+  if (live && sub == 0) {
+    b.x[env] = s.x;
+    b.y[env] = s.y;
+    b.theta[env] = s.theta;
+    b.velocity[env] = s.velocity;
+    b.steering[env] = s.steering;
+    b.radius[env] = s.radius;
+    b.front_x[env] = s.front_x;
+    b.front_y[env] = s.front_y;
+#pragma unroll
+    for (int i = 0; i < 8; i++) b.local_path[env * 8 + i] = s.lp[i];
+    b.lp_len[env] = s.lp_len;
+    b.last_maneuver[env] = s.last_maneuver;
+    b.cte[env] = cte;
+    b.heading_error[env] = he;
+    b.reward[env] = reward;
+    b.terminated[env] = (unsigned char)terminated;
+    b.truncated[env] = (unsigned char)trunc;
+    b.status[env] = status;
+    if (b.needs_reset) b.needs_reset[env] = (unsigned char)nr;
+    if (cursor != cursor0) b.spawn_cursor[env] = cursor;
+  }
+  if (live && s1.a.term_counters && sub < s1.a.n_terms) s1.a.term_counters[(size_t)env * TC_MAX_TERMS + sub] = gl.cnt[sub];
+}
+
 // One (step, env) frame per workgroup: camera stage from the pose the simulate launch left, then the raster stage.
 // Frames do not depend on each other, a launch has steps x N of them -- many more than the chip holds at once -- and
 // their cost varies 8-fold with what is in view, so the dispatcher's hand-out of the next frame to the next free slot is
@@ -1834,6 +2100,11 @@ struct tc_env {
   // env (measured on cfg3: 70.9 us per step against a mean of 41 us per wavefront-step).  Frames are independent of
   // each other, and K x N workgroups are many more than the chip holds at once, so the dispatcher balances them.
   int multi_split;
+  int chunk;        // K-step calls with a rollout: steps per simulate launch when the call is pipelined (TC_CHUNK, 0 = off)
+  hipStream_t frame_stream;
+  hipEvent_t sim_ev, frames_ev;
+  int prof_piped[TC_PROF_RING];
+  int env_grouped;  // K-step calls: simulate with tc_envg_kernel (TC_EL lanes per env); TC_ENV_GROUPED=0 keeps one wavefront per env
   int *segm_g, *segm_n;  // [segm_rows][N][seg_cap][5], [segm_rows][N]
   double* pose_rows;     // [segm_rows][N][4]
   int segm_rows;
@@ -1849,7 +2120,7 @@ struct tc_env {
   unsigned char* noise_hw;
   unsigned long long noise_seed;
   unsigned int* noise_step;  // device counter
-  hipEvent_t ev[3][TC_PROF_RING];
+  hipEvent_t ev[4][TC_PROF_RING];  // start, simulate done, all done, first frame launch (pipelined calls)
 };
 
 template <typename T>
@@ -1929,6 +2200,7 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
   std::vector<int2> edges(TE), lpe(lpE), edges_g(TE);
   std::vector<int> edge_layer(TE);
   std::vector<double> of(TE), orv(TE), lpo(lpE), nori(lpE), pori(lpE);
+  std::vector<double4> exy(TE);
   std::vector<int> noff(lpN + 1, 0), poff(lpN + 1, 0), nnode(lpE), pnode(lpE);
   for (int i = 0; i < TN; i++) nodes[i] = make_double2(desc->nodes[2 * i], desc->nodes[2 * i + 1]);
   for (int l = 0; l < C; l++)
@@ -1941,6 +2213,7 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
       // static halves of layer.py:140-141, evaluated with the host libm like the reference does
       of[e] = atan2(evy, evx);
       orv[e] = atan2(-evy, -evx);
+      exy[e] = make_double4(a.x, a.y, b.x, b.y);
     }
   for (int i = 0; i < lpN; i++) lpn[i] = make_double2(desc->lanepath_nodes[2 * i], desc->lanepath_nodes[2 * i + 1]);
   for (int e = 0; e < lpE; e++) {
@@ -1995,7 +2268,7 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
   HIP_TRY(hipGetDevice(&m->device));
 #define UP(vec, field)                                             \
   if (rc == TC_OK) rc = upload(m, vec, &d.field);
-  UP(fat, lp_fat) UP(nodes, nodes) UP(edges, edges) UP(edges_g, edges_g) UP(edge_layer, edge_layer) UP(of, ori_fwd) UP(orv, ori_rev) UP(lpn, lp_nodes) UP(lpe, lp_edges)
+  UP(fat, lp_fat) UP(nodes, nodes) UP(edges, edges) UP(edges_g, edges_g) UP(edge_layer, edge_layer) UP(of, ori_fwd) UP(orv, ori_rev) UP(exy, edge_xy) UP(lpn, lp_nodes) UP(lpe, lp_edges)
   UP(lpo, lp_ori) UP(noff, next_off) UP(nnode, next_node) UP(nori, next_ori) UP(poff, prev_off)
   UP(pnode, prev_node) UP(pori, prev_ori)
 #undef UP
@@ -2045,6 +2318,20 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   if (const char* fu = getenv("TC_FUSE")) e->fuse = atoi(fu) != 0;
   e->multi_split = 1;
   if (const char* ms = getenv("TC_MULTI_SPLIT")) e->multi_split = atoi(ms) != 0;
+  e->env_grouped = 1;
+  if (const char* eg = getenv("TC_ENV_GROUPED")) e->env_grouped = atoi(eg) != 0;
+  e->chunk = 16;
+  if (const char* ch = getenv("TC_CHUNK")) e->chunk = atoi(ch) > 0 ? atoi(ch) : 0;
+  e->frame_stream = nullptr;
+  e->sim_ev = e->frames_ev = nullptr;
+  memset(e->prof_piped, 0, sizeof(e->prof_piped));
+  if (hipStreamCreateWithFlags(&e->frame_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->sim_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->frames_ev, hipEventDisableTiming) != hipSuccess) {
+    set_err("tc_env_create: cannot create the internal frame stream");
+    delete e;
+    return TC_E_HIP;
+  }
   e->segm_g = e->segm_n = nullptr;
   e->pose_rows = nullptr;
   e->segm_rows = 0;
@@ -2230,7 +2517,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
 extern "C" int tc_env_profile(tc_env* e, int32_t enable) {
   if (!e) return TC_E_INVALID;
   if (enable && !e->ev[0][0]) {
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 4; k++)
       for (int i = 0; i < TC_PROF_RING; i++) HIP_TRY(hipEventCreate(&e->ev[k][i]));
   }
   e->prof = enable > 0 ? enable : 0;
@@ -2247,7 +2534,8 @@ extern "C" int tc_env_profile_read(tc_env* e, double* sim_us, double* raster_us,
     float t0 = 0, t1 = 0;
     HIP_TRY(hipEventSynchronize(e->ev[2][i]));
     HIP_TRY(hipEventElapsedTime(&t0, e->ev[0][i], e->ev[1][i]));
-    HIP_TRY(hipEventElapsedTime(&t1, e->ev[1][i], e->ev[2][i]));
+    // pipelined K-step call: the frame launches run beside the simulate launches, from their own start event
+    HIP_TRY(hipEventElapsedTime(&t1, e->prof_piped[i] ? e->ev[3][i] : e->ev[1][i], e->ev[2][i]));
     a += t0;
     b += t1;
   }
@@ -2259,7 +2547,7 @@ extern "C" int tc_env_profile_read(tc_env* e, double* sim_us, double* raster_us,
 
 extern "C" int tc_env_destroy(tc_env* e) {
   if (e && e->ev[0][0])
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 4; k++)
       for (int i = 0; i < TC_PROF_RING; i++) (void)hipEventDestroy(e->ev[k][i]);
   if (e) {
     for (int p = 1; p < TC_MAX_SPLIT; p++) {
@@ -2267,6 +2555,9 @@ extern "C" int tc_env_destroy(tc_env* e) {
       if (e->join_ev[p]) (void)hipEventDestroy(e->join_ev[p]);
     }
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+    if (e->frame_stream) (void)hipStreamDestroy(e->frame_stream);
+    if (e->sim_ev) (void)hipEventDestroy(e->sim_ev);
+    if (e->frames_ev) (void)hipEventDestroy(e->frames_ev);
   }
   if (e && e->segm_g) (void)hipFree(e->segm_g);
   if (e && e->segm_n) (void)hipFree(e->segm_n);
@@ -2600,6 +2891,15 @@ static int noise_advance(tc_env* e, int mode, bool rendered, int nsteps, void* s
   return TC_OK;
 }
 
+// steps per simulate / frame dispatch of a K-step call that renders every step (see launch()): TC_CHUNK, or a quarter
+// of the call when that is less; nsteps when the call is not pipelined
+static int chunk_steps(const tc_env* e, int nsteps, bool frames, bool all) {
+  const bool can_pipe = frames && e->env_grouped && e->chunk > 0 && all && nsteps > 1;
+  if (!can_pipe) return nsteps;
+  const int q = (nsteps + 3) / 4;
+  return e->chunk < q ? e->chunk : (q < 2 ? 2 : q);
+}
+
 static bool fused_path(const tc_env* e, uint32_t flags) {
   const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
   return do_raster && e->fuse && e->kvar != 13;
@@ -2675,62 +2975,111 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     }
     const bool frames = e->fuse && kv != 13;  // camera + raster per frame (tc_frame_kernel); else camera in the simulate
                                               // launch (the register-hungry K = 13 stage, TC_FUSE=0) and a raster launch
-    StepArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.a = e->k;
-    sa.a.env0 = 0;
-    sa.a.seg_g = e->segm_g;
-    sa.a.seg_n = e->segm_n;
-    sa.ma = ma;
-    sa.ma.seg_rows = nsteps;
-    sa.ma.cam_here = frames ? 0 : 1;
-    sa.ma.pose_rows = frames ? e->pose_rows : nullptr;
-    sa.mode = mode;
-    sa.cdtype = cdtype;
-    sa.flags = flags;
-    sa.car_control = cc;
-    sa.maneuver = man;
-    sa.spawn_nodes = spawn;
-    sa.mask = mask;
-    hipLaunchKernelGGL(frames ? kern_nocam : kern, dim3(N), dim3(TC_NT), e->k.lds.total, main, sa);
-    HIP_TRY(hipGetLastError());
-    if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
-    // with a rollout every step's frame is wanted; without one only the last survives in the bound buffer
-    const bool all = roll && roll->obs;
-    RArgs r = make_rargs(e, e->segm_g, e->segm_n, e->k.seg_cap, nullptr, flags, 0, all ? roll->obs : nullptr, mode == MODE_STEP);
-    r.seg_row0 = all ? 0 : nsteps - 1;
-    r.obs_row_stride = all ? (long long)N * (long long)e->obs_bytes : 0;
-    const int rows = all ? nsteps : 1;
-    const bool thick = r.cam.thickness > 1, cls = r.cam.format == TC_FMT_CLASSES;
+    // Pipelining inside the call.  The steps are issued in chunks: the simulate launch of chunk c+1 runs on the caller's
+    // stream while the frames of chunk c are produced on an internal stream (joined back before the call's work ends
+    // on the caller's stream, so the caller still sees everything complete in stream order).  The two kernels suit
+    // each other: the frame kernel is bound by vector issue, the grouped simulate kernel by latency (512 wavefronts
+    // for 4096 envs), so the second hides in the first's shadow instead of adding its 21 us per step.
+    const bool all = roll && roll->obs;  // with a rollout every step's frame is wanted; else only the last survives
+    // Chunks of TC_CHUNK (16) steps, or a quarter of the call when that is less, so that a short call (the 20 steps of a
+    // smoke benchmark) still has several chunks in flight.  The first simulate launch is the one thing nothing overlaps
+    // with; starting with 1, 2, 4, ... steps to shorten it (TC_RAMP=1) was measured and is slower: frame launches of
+    // one or two steps are too small for the dispatcher to balance (cfg3, 20 / 40 / 100-step calls: 53.2 / 47.9 / 40.1 us
+    // per step with the ramp, 50.3 / 43.7 / 39.5 with equal chunks; 50.9 with no pipelining at all).
+    const bool can_pipe = frames && e->env_grouped && e->chunk > 0 && all && nsteps > 1;
+    static const int ramp = getenv("TC_RAMP") ? atoi(getenv("TC_RAMP")) : 0;
+    int chunk = (can_pipe && ramp) ? 1 : chunk_steps(e, nsteps, frames, all);
+    const bool piped = can_pipe;
+    hipStream_t fs = piped ? e->frame_stream : main;
+    const size_t esz = cdtype == TC_F32 ? 4 : 8;
+    const bool thick = e->k.cam.thickness > 1, cls = e->k.cam.format == TC_FMT_CLASSES;
     (void)thick;
     (void)cls;
-    for (int row0 = 0; row0 < rows; row0 += 65535) {  // grid.y limit
-      RArgs rr = r;
-      rr.seg_row0 = r.seg_row0 + row0;
-      rr.obs += (size_t)row0 * (size_t)r.obs_row_stride;
-      const int ny = rows - row0 < 65535 ? rows - row0 : 65535;
-      if (frames) {
-        FrameArgs fa;
-        memset(&fa, 0, sizeof(fa));
-        fa.a = sa.a;
-        fa.r = rr;
-        fa.pose_rows = e->pose_rows;
-        frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
-        hipLaunchKernelGGL(fk, dim3(N, ny), dim3(TC_NT), e->k.lds.total, main, fa);
-      } else {
-#ifdef TC_DEV_FAST
-        auto rk = tc_raster_kernel<true, TC_FMT_CLASSES>;
-#else
-        auto rk = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
-                        : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
-#endif
-        hipLaunchKernelGGL(rk, dim3(N, ny), dim3(TC_NT), e->r_lds, main, rr);
+    bool first_frames = true;
+    for (int c0 = 0, cn = 0; c0 < nsteps; c0 += cn, chunk = !(can_pipe && ramp) ? chunk : (chunk * 2 <= e->chunk ? chunk * 2 : e->chunk)) {
+      cn = nsteps - c0 < chunk ? nsteps - c0 : chunk;
+      const size_t r0 = (size_t)c0 * N;  // first [step][env] row of this chunk
+      StepArgs sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.a = e->k;
+      sa.a.env0 = 0;
+      sa.a.seg_g = e->segm_g + r0 * e->k.seg_cap * 5;
+      sa.a.seg_n = e->segm_n + r0;
+      sa.ma = ma;
+      sa.ma.nsteps = cn;
+      sa.ma.seg_rows = cn > 1 ? cn : 2;  // (> 1: row k of the chunk's lists; a one-step chunk still writes row 0 of them)
+      sa.ma.cam_here = frames ? 0 : 1;
+      sa.ma.pose_rows = frames ? e->pose_rows + r0 * 4 : nullptr;
+      if (roll) {
+        sa.ma.roll.obs = roll->obs ? roll->obs + r0 * (size_t)e->obs_bytes : nullptr;
+        sa.ma.roll.reward = roll->reward ? roll->reward + r0 : nullptr;
+        sa.ma.roll.terminated = roll->terminated ? roll->terminated + r0 : nullptr;
+        sa.ma.roll.truncated = roll->truncated ? roll->truncated + r0 : nullptr;
+        sa.ma.roll.cte = roll->cte ? roll->cte + r0 : nullptr;
+        sa.ma.roll.heading_error = roll->heading_error ? roll->heading_error + r0 : nullptr;
       }
+      sa.mode = mode;
+      sa.cdtype = cdtype;
+      sa.flags = flags;
+      sa.car_control = (const char*)cc + r0 * 2 * esz;
+      sa.maneuver = man + r0;
+      sa.spawn_nodes = spawn;
+      sa.mask = mask;
+      if (frames && e->env_grouped)
+        hipLaunchKernelGGL(tc_envg_kernel, dim3((N + TC_NT / TC_EL - 1) / (TC_NT / TC_EL)), dim3(TC_NT), 0, main, sa);
+      else
+        hipLaunchKernelGGL(frames ? kern_nocam : kern, dim3(N), dim3(TC_NT), e->k.lds.total, main, sa);
       HIP_TRY(hipGetLastError());
+      const bool last_chunk = c0 + cn >= nsteps;
+      if (prof && last_chunk) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
+      if (!all && !last_chunk) continue;  // only the last step's frame is wanted
+      if (piped) {
+        HIP_TRY(hipEventRecord(e->sim_ev, main));
+        HIP_TRY(hipStreamWaitEvent(fs, e->sim_ev, 0));
+      }
+      if (prof && first_frames && piped) HIP_TRY(hipEventRecord(e->ev[3][slot], fs));
+      first_frames = false;
+      RArgs r = make_rargs(e, e->segm_g, e->segm_n, e->k.seg_cap, nullptr, flags, 0, all ? roll->obs + r0 * (size_t)e->obs_bytes : nullptr,
+                           mode == MODE_STEP);
+      r.seg_row0 = all ? c0 : nsteps - 1;  // absolute step index of the call: draw-list / pose row and blob stream position
+      r.obs_row_stride = all ? (long long)N * (long long)e->obs_bytes : 0;
+      const int rows = all ? cn : 1;
+      for (int row0 = 0; row0 < rows; row0 += 65535) {  // grid.y limit
+        RArgs rr = r;
+        rr.seg_row0 = r.seg_row0 + row0;
+        rr.obs += (size_t)row0 * (size_t)r.obs_row_stride;
+        const int ny = rows - row0 < 65535 ? rows - row0 : 65535;
+        if (frames) {
+          FrameArgs fa;
+          memset(&fa, 0, sizeof(fa));
+          fa.a = e->k;
+          fa.a.env0 = 0;
+          fa.a.seg_g = e->segm_g;
+          fa.a.seg_n = e->segm_n;
+          fa.r = rr;
+          fa.pose_rows = e->pose_rows;
+          frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
+          hipLaunchKernelGGL(fk, dim3(N, ny), dim3(TC_NT), e->k.lds.total, fs, fa);
+        } else {
+#ifdef TC_DEV_FAST
+          auto rk = tc_raster_kernel<true, TC_FMT_CLASSES>;
+#else
+          auto rk = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
+                          : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
+#endif
+          hipLaunchKernelGGL(rk, dim3(N, ny), dim3(TC_NT), e->r_lds, fs, rr);
+        }
+        HIP_TRY(hipGetLastError());
+      }
     }
     if (prof) {
-      HIP_TRY(hipEventRecord(e->ev[2][slot], main));
+      HIP_TRY(hipEventRecord(e->ev[2][slot], fs));
+      e->prof_piped[slot] = piped ? 1 : 0;
       e->prof_n++;
+    }
+    if (piped) {
+      HIP_TRY(hipEventRecord(e->frames_ev, fs));
+      HIP_TRY(hipStreamWaitEvent(main, e->frames_ev, 0));
     }
     return noise_advance(e, mode, true, nsteps, stream);
   }
@@ -2781,6 +3130,8 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     sa.maneuver = man;
     sa.spawn_nodes = spawn;
     sa.mask = mask;
+    // (K steps without observations run on the one-wavefront-per-env kernel: with nothing to share the chip with, its
+    // shorter serial chain wins -- cfg2: 16.5 us per step against 20.7 for the grouped kernel)
     hipLaunchKernelGGL(do_raster ? kern : kern_nocam, dim3(env1 - env0), dim3(TC_NT), k.lds.total, st, sa);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
@@ -2822,17 +3173,21 @@ extern "C" int tc_step_multi(tc_env* e, const void* car_control, int32_t control
   return launch(e, MODE_STEP, car_control, control_dtype, maneuver, nullptr, nullptr, flags, stream, n_steps, rollout);
 }
 
-extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar, char* name,
-                                  int32_t name_cap) {
+extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar,
+                                  int32_t* steps_per_dispatch, char* name, int32_t name_cap) {
   if (!e) return TC_E_INVALID;
   const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
   const bool f = fused_path(e, flags) && e->split == 1 && !(n_steps > 1 && e->multi_split);
   if (fused) *fused = f ? 1 : 0;
   if (kvar) *kvar = e->kvar;
   const bool frames = n_steps > 1 && do_raster && !f && e->fuse && e->kvar != 13;
+  if (steps_per_dispatch) *steps_per_dispatch = f ? n_steps : chunk_steps(e, n_steps, frames, true);
   if (name && name_cap > 0)
     snprintf(name, (size_t)name_cap, "%s",
-             f ? "tc_step_kernel" : frames ? "tc_env_kernel+tc_frame_kernel" : do_raster ? "tc_env_kernel+tc_raster_kernel" : "tc_env_kernel");
+             f ? "tc_step_kernel"
+               : frames ? (e->env_grouped ? "tc_envg_kernel+tc_frame_kernel" : "tc_env_kernel+tc_frame_kernel")
+               : do_raster ? "tc_env_kernel+tc_raster_kernel"
+                           : "tc_env_kernel");
   return TC_OK;
 }
 

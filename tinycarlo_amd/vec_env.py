@@ -507,10 +507,10 @@ class TinyCarloVecEnv(gym.Env):
 
     def launch_info(self, n_steps: int = 1) -> Dict[str, Any]:
         """What a call of n_steps steps launches with the current settings (tc_env_launch_info): for benchmark labels."""
-        f, kv, name = C.c_int32(), C.c_int32(), C.create_string_buffer(64)
-        nat.check(nat.lib().tc_env_launch_info(self._h, self._flags(), int(n_steps), C.byref(f), C.byref(kv), name, 64),
-                  "tc_env_launch_info")
-        return {"fused": bool(f.value), "kvar": kv.value, "kernel": name.value.decode()}
+        f, kv, spd, name = C.c_int32(), C.c_int32(), C.c_int32(), C.create_string_buffer(64)
+        nat.check(nat.lib().tc_env_launch_info(self._h, self._flags(), int(n_steps), C.byref(f), C.byref(kv), C.byref(spd),
+                                               name, 64), "tc_env_launch_info")
+        return {"fused": bool(f.value), "kvar": kv.value, "kernel": name.value.decode(), "steps_per_dispatch": spd.value}
 
     def request_reset(self, mask: torch.Tensor) -> None:
         """Marks envs for re-spawning at the start of the next autoreset step, in addition to the ones the engine

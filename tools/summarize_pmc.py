@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
 """gpurun_out/pmc_<tag>/p*/**/_counter_collection.csv -> profiles/<round>/<name>_pmc.json (per kernel, per-launch means)
 and gpurun_out/prof_<tag>/**/_kernel_stats.csv -> profiles/<round>/<name>_kernel_stats.csv (tc_* rows only).
-usage: python tools/summarize_pmc.py <tag> <name> [--round r02] [--steps-per-launch 32] [--build <git hash>]"""
+usage: python tools/summarize_pmc.py <tag> <name> [--round r02] [--rows-per-dispatch 16] [--build <git hash>]"""
 import argparse, collections, csv, glob, json, os
 ap = argparse.ArgumentParser()
 ap.add_argument("tag"); ap.add_argument("name")
-ap.add_argument("--round", default="r02"); ap.add_argument("--steps-per-launch", type=int, default=32); ap.add_argument("--build", default="?")
+ap.add_argument("--round", default="r02"); ap.add_argument("--rows-per-dispatch", type=float, default=16, help="steps one dispatch of the workload's kernels covers (launch_info steps_per_dispatch)"); ap.add_argument("--build", default="?")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles", a.round)
 os.makedirs(out, exist_ok=True)
-KINDS = ("tc_frame_kernel", "tc_step_kernel", "tc_raster_kernel", "tc_env_kernel", "tc_noise_kernel")
+KINDS = ("tc_frame_kernel", "tc_step_kernel", "tc_raster_kernel", "tc_envg_kernel", "tc_env_kernel", "tc_noise_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 grid = {}
 for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{a.tag}", "p*", "*", "*_counter_collection.csv")):
@@ -32,7 +32,7 @@ for k, gs in by_kernel.items():
     res[k]["_grid_size"] = g
     res[k]["_dispatches_averaged"] = max(len(v) for v in gs[g].values())
 res["_note"] = "per-launch means over the profiled launches of the most frequent grid size; FETCH_SIZE/WRITE_SIZE in KB as rocprofv3 reports them"
-res["_steps_per_launch"] = a.steps_per_launch
+res["_rows_per_dispatch"] = a.rows_per_dispatch
 res["_build"] = a.build
 json.dump(res, open(os.path.join(out, f"{a.name}_pmc.json"), "w"), indent=1, sort_keys=True)
 rows = []
