@@ -292,7 +292,9 @@ def main():
     # event triple on every launch of a long one serialises the queue)
     n_launch = K if M == 0 else -(-K // M)
     env.profile(1 if n_launch <= 64 else max(1, n_launch // 48))
-    dt, ev_ms, n_l = timed(W, K)
+    # the timed region starts on a call boundary of the cyclic action buffer, so that no call is split at its wrap-around
+    t_start = W if M == 0 else (-(-W // M) * M) % period
+    dt, ev_ms, n_l = timed(t_start, K)
     prof = env.profile_read()
     env.profile(0)
 
@@ -330,7 +332,8 @@ def main():
     b_obs = 0 if w["no_obs"] else (C * H * Wd if w["fmt"] == "classes" else 3 * H * Wd)
     bytes_per_env_step = B_STATE + b_obs
     step_s = ev_ms / 1e3 / K  # HIP events on the launch stream around the K timed steps
-    info = env.launch_info(max(M, 1))  # what the library really launches (not guessed from timings)
+    steps_per_call = max(1, int(round(K / max(n_l, 1)))) if M >= 1 else 1
+    info = env.launch_info(steps_per_call)  # what the library really launches for a call of that size (not guessed from timings)
     kname = info["kernel"]
     fused = info["fused"]
     full_launches = (K // M) if M >= 1 else K      # the sampled means below include a short last call if K % M != 0
@@ -338,21 +341,22 @@ def main():
     # A K-step call that stores every frame is issued as pipelined chunks (include/tinycarlo_hip.h, tc_step_multi): the
     # library reports how many steps one kernel DISPATCH covers, and the roofline below is per dispatch, the unit
     # rocprofv3's kernel trace and PMC counters are in.
-    spd = max(1, min(info.get("steps_per_dispatch", 1), max(M, 1)))
+    spd = max(1, min(info["steps_per_dispatch"], steps_per_call))
     n_disp = -(-int(round(steps_in_sampled)) // spd) if M >= 1 else 1
     rows_per_dispatch = steps_in_sampled / n_disp
     two = "+" in kname                             # simulate dispatches + frame (or raster) dispatches
     if two:
         # The dominant kernel is the one that writes the observations (tc_frame_kernel: camera + raster of one frame per
-        # workgroup).  Its algorithmic bytes per frame: the observation, written once, plus the 32-byte pose row it
-        # reads; the 240 B of state / action / info traffic belong to the simulate dispatch in front of it.
+        # workgroup).  Its algorithmic bytes per frame: the observation, written once, plus the 96 bytes of the 3x4 pose
+        # matrix it reads; the 240 B of state / action / info traffic belong to the simulate dispatch in
+        # front of it.
         # HIP events bracket the call's first..last frame dispatch on the stream they run on; the dispatches follow
         # each other without a gap there (simulating a chunk is faster than drawing it), so span / dispatches is the
         # average dispatch duration -- the figure rocprofv3's kernel stats give for the same command.
         dom = kname.split("+")[-1]
         kernel_s = prof["raster_us"] * 1e-6 / n_disp
         sim_s = prof["simulate_us"] * 1e-6 / n_disp
-        dom_bytes_per_frame = b_obs + 32
+        dom_bytes_per_frame = b_obs + 96
     else:
         dom = kname
         kernel_s = sim_s = prof["simulate_us"] * 1e-6 / n_disp

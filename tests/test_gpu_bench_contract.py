@@ -40,8 +40,8 @@ def test_default_workload_line():
     # roofline is per kernel dispatch (rocprofv3's unit), i.e. per chunk
     assert d["config"]["entry_point"] == "tc_step_multi" and d["config"]["launches_timed"] == 1 and r["steps_per_call"] == 40
     assert r["steps_per_dispatch"] == 10 and r["dispatches_per_call"] == 4
-    assert r["algorithmic_bytes_per_unit"] == 5 * 64 * 64 + 32     # a frame: the observation + the pose row it is drawn from
-    assert r["algorithmic_bytes_per_launch"] == 10 * 4096 * (5 * 64 * 64 + 32)
+    assert r["algorithmic_bytes_per_unit"] == 5 * 64 * 64 + 96     # a frame: the observation + the pose matrix it is drawn from
+    assert r["algorithmic_bytes_per_launch"] == 10 * 4096 * (5 * 64 * 64 + 96)
     assert abs(r["kernel_us_per_step"] * 10 - r["kernel_us"]) < 1e-6 * r["kernel_us"]
     assert abs(r["kernels_us"]["tc_frame_kernel"] - r["kernel_us"]) < 1e-9
     assert abs(r["step_frac"] - (240 + 5 * 64 * 64) * 4096 / (r["step_us"] * 1e-6) / 8e12) < 1e-9
@@ -60,7 +60,7 @@ def test_other_workloads_and_flags():
     assert d["config"]["envs_per_gpu"] == 256 and d["roofline"]["traffic"] is None     # PMC summary is for the full size only
     assert d["roofline"]["kernel"] == "tc_frame_kernel"    # knuffingen: the K = 9 variant, two camera layer groups
     assert d["roofline"]["dispatches_per_call"] == 4       # 10 steps: chunks of 3, 3, 3, 1
-    assert d["roofline"]["algorithmic_bytes_per_launch"] == 2.5 * 256 * (5 * 128 * 128 + 32)
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 2.5 * 256 * (5 * 128 * 128 + 96)
     # the single-step entry point stays measurable: one tc_step launch per step
     d = _run("--steps", "16", "--warmup", "4", "--steps-per-launch", "0", "--no-cpu-baseline")
     assert d["config"]["entry_point"] == "tc_step" and d["roofline"]["steps_per_dispatch"] == 1

@@ -45,6 +45,21 @@ struct DevMap {
   const double* ori_rev;  // per lane-line edge: atan2(-evy, -evx)
   const double4* edge_xy; // per lane-line edge: both end points (n0.x, n0.y, n1.x, n1.y) in one 32-byte record, so that a
                           // scan over edges is one independent load per edge instead of edge -> two dependent node loads
+  // Candidate grid for layer.py:33-44 (nearest edge = first minimum of |d(p, n0) + d(p, n1)| over a layer's edges).
+  // A uniform grid of square cells over the map's bounding box + margin; for cell c and layer l the host lists, in
+  // ascending edge order, every edge that can attain the minimum for SOME point of the cell: with f_c(e) the value at the
+  // cell centre and r the half diagonal, |f_p(e) - f_c(e)| <= 2 r for every p in the cell (each of the two distances
+  // moves by at most |p - centre|), so the minimising edge of p satisfies f_c(e) <= min_e f_c(e) + 4 r.  Scanning the
+  // list with the same strict `<` as the full scan therefore returns the same edge, ties included (every edge that
+  // attains the minimum is in the list).  Points outside the grid (or non-finite) take the full scan.
+  // The grid reaches 4 m beyond the lane lines (under random actions ~2 % of the cars are more than 1 m off the road at any
+  // time and the furthest about 3.3 m: beyond 10 track widths of cross-track error the default env terminates).  It has to
+  // cover them: in the grouped kernel a wavefront whose envs took different paths -- candidates for seven, the full scan
+  // for one -- pays for both, and a launch lasts as long as its slowest wavefront.
+  int grid_nx, grid_ny;          // 0: no grid (empty map, non-finite coordinates)
+  double grid_x0, grid_y0, grid_inv;  // cell (ix, iy) = floor((p - origin) * grid_inv)
+  const int* cand_off;           // [grid_nx * grid_ny * C + 1]: entries of (cell, layer) are cand_idx[off[cell*C+l] .. off[cell*C+l+1])
+  const int* cand_idx;           // global lane-line edge ids (edge_off[l] + local id)
   unsigned char colors[16][3];
   int lpN, lpE;
   int first_spawnable;    // a lanepath node with an out-edge (fallback for invalid spawn requests)
@@ -305,6 +320,13 @@ __device__ inline int d_nearest_edge_with_orientation(const DevMap& m, double px
   return best;
 }
 
+// cell of the candidate grid holding p, or -1 (no grid, p outside it or not finite): see DevMap
+__device__ __forceinline__ int d_grid_cell(const DevMap& m, double px, double py) {
+  const double gx = (px - m.grid_x0) * m.grid_inv, gy = (py - m.grid_y0) * m.grid_inv;
+  const bool in = m.grid_nx > 0 && gx >= 0.0 && gx < (double)m.grid_nx && gy >= 0.0 && gy < (double)m.grid_ny;
+  return in ? (int)gy * m.grid_nx + (int)gx : -1;
+}
+
 // lowest-index argmin among the EL lanes of an aligned lane group (EL a power of two < 64): xor butterfly, after which
 // every lane of the group holds the result.  All lanes of a group must be active (group-uniform control flow).
 template <int EL>
@@ -317,6 +339,35 @@ __device__ __forceinline__ void group_argmin(double& v, int& idx) {
     v = take ? ov : v;
     idx = take ? oi : idx;
   }
+}
+
+// The same reduction for groups of 8 lanes and TC_AG independent (value, index) pairs, with DPP moves -- register to
+// register inside the SIMD (quad_perm xor 1, quad_perm xor 2, row_half_mirror i <-> 7 - i) -- instead of ds_bpermute
+// round trips through the LDS crossbar (~1.1 k clocks per reduction in the grouped simulate kernel, five per step).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ void group8_argmin_stage(double (&bd)[TC_AG], int (&best)[TC_AG]) {
+#pragma unroll
+  for (int g = 0; g < TC_AG; g++) {
+    const double ov = dpp_d<CTRL>(bd[g]);
+    const int oi = dpp_i<CTRL>(best[g]);
+    const bool take = (oi >= 0) && (best[g] < 0 || ov < bd[g] || (ov == bd[g] && oi < best[g]));
+    bd[g] = take ? ov : bd[g];
+    best[g] = take ? oi : best[g];
+  }
+}
+__device__ __forceinline__ void group8_argmin_multi(double (&bd)[TC_AG], int (&best)[TC_AG]) {
+  group8_argmin_stage<0xB1>(bd, best);   // quad_perm [1,0,3,2]
+  group8_argmin_stage<0x4E>(bd, best);   // quad_perm [2,3,0,1]
+  group8_argmin_stage<0x141>(bd, best);  // row_half_mirror: the other quad of the 8
 }
 
 // layer.py:59-74 over the lanepath by the EL lanes of one env's group (sub = lane within the group)

@@ -111,6 +111,25 @@ __device__ long long* tc_tstamp = nullptr;  // [N][32]
 #define DBG_SKIP_LINESETUP 0x20000u
 #define DBG_SKIP_SLOPE 0x40000u
 #define DBG_SKIP_QUAD 0x80000u
+#define DBG_SKIP_CLIP 0x100000u
+#define DBG_SKIP_DRAWLIST 0x200000u
+// the kernels test them only in the ablation build (make dev-ablate): in the shipped library every test folds to false,
+// so the switches cost no scalar registers there (they were ~25 live conditions at the head of the raster stage)
+#ifdef TC_ABLATE
+#define DBG_ON(word, f) (((word) & (f)) != 0)
+#else
+#define DBG_ON(word, f) false
+#endif
+
+// A reference into the kernel-argument segment, passed through an empty asm: the compiler can no longer tell that two
+// reads go to the same block, so values loaded behind this point are not merged with (and kept alive from) earlier
+// loads, nor hoisted out of the loop the call sits in -- they are s_load'ed where they are used.
+template <class T>
+__device__ __forceinline__ const T& kernarg_again(const T& r) {
+  unsigned long long p = (unsigned long long)&r;
+  asm volatile("" : "+s"(p));
+  return *(const T*)(const __attribute__((address_space(4))) T*)p;
+}
 
 #define RB 32        // segments rasterised per batch
 // raster-stage LDS layout (compile-time: folds into instruction offsets and frees SGPRs)
@@ -177,6 +196,7 @@ struct KArgs {
   const int* spawn_tab;  // TC_F_DEVICE_SPAWN: spawnable candidate nodes (library owned), spawn_n > 0 entries
   int spawn_n;
   unsigned long long spawn_seed;
+  unsigned int dbg;  // DBG_* ablation switches for the camera stage of tc_frame_kernel (0 in every other launch)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -350,6 +370,202 @@ __device__ __forceinline__ void cam_move_to_plane(double* Px, double* Py, double
   }
 }
 
+// The exact replay of one fix-up pass from its list of n straddling edges (edge id, target | other << 16): every target
+// node's chain of moves in ascending edge index, run by the lane that holds the chain's first edge.  range_too: the
+// target's idx_in_range bit is refreshed from its new depth (camera.py:80 reads the depths passes 1-2 left behind).
+__device__ inline void cam_chain_replay(double* Px, double* Py, double* Pz, unsigned char* flg, int bit, double tz,
+                                        const int* list, int n, double max_range, bool range_too, int tid) {
+  for (int k = tid; k < n; k += TC_NT) {
+    const int e = list[2 * k];
+    const int t = list[2 * k + 1] & 0xffff;
+    bool first = true;
+    for (int j = 0; j < n; j++)
+      if ((list[2 * j + 1] & 0xffff) == t && list[2 * j] < e) first = false;
+    if (!first) continue;
+    int cur = e, o = (unsigned)list[2 * k + 1] >> 16;  // the end that stays
+    for (int guard = 0; guard < n; guard++) {
+      cam_move_to_plane(Px, Py, Pz, o, t, tz);
+      int nxt = 0x7fffffff, no = 0;
+      for (int j = 0; j < n; j++) {
+        const int ej = list[2 * j], pj = list[2 * j + 1];
+        if ((pj & 0xffff) == t && ej > cur && ej < nxt) {
+          nxt = ej;
+          no = (unsigned)pj >> 16;
+        }
+      }
+      if (nxt == 0x7fffffff) break;
+      cur = nxt;
+      o = no;
+    }
+    unsigned int f = flg[t] | (unsigned)bit;
+    if (range_too) f = (f & ~2u) | (Pz[t] > -max_range ? 2u : 0u);
+    flg[t] = (unsigned char)f;
+  }
+}
+
+__device__ inline int2 cam_project(const double* K, double X, double Y, double Z, double& u, double& v);
+
+// rank of this lane among the set bits of a wave ballot
+__device__ __forceinline__ int wave_rank(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// Phase C of one camera group whose nodes and edges sit in the wavefront's registers (one window: every bundled map).
+// camera.py:52-110 reads the whole node / edge arrays in each of its steps; here the flags of an edge's two ends are
+// carried in a register per edge slot (`ff`) and refreshed only after a pass that moved something, so a fix-up pass in
+// which no edge straddles the plane -- or only a handful, the usual case -- costs a few compares per slot instead of a
+// round of LDS traffic, and the straddling edges are compacted (ballot + mbcnt, no atomics) so that the move code runs
+// ONCE per pass, on the low lanes, instead of once per register slot.
+//   idx_in_range (camera.py:80) is evaluated on the depths left by passes 1-2: it is set here from the transformed depth
+// and refreshed for exactly the nodes those passes move -- the same values, without a pass over all nodes.
+// Appends the group's visible edges to the draw list at segg[5 * nseg ...] and advances nseg (wave-uniform).
+template <int K>
+__device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>& mc, const double* pose, const double* Kc,
+                                               const int l0, const int l1, const int ge0, const int nn, const int ne,
+                                               double* Px, double* Py, double* Pz, unsigned char* flg, int* list,
+                                               int* segg, int& nseg, unsigned int& my_layers, const int env, const int tid) {
+  const DevMap& m = a.m;
+  const DevCam& cam = a.cam;
+  const double max_range = cam.max_range;
+#pragma unroll
+  for (int k = 0; k < K; k++) {  // camera.py:124-131, 70, 80
+    const int i = k * TC_NT + tid;
+    if (i < nn) {
+      double h[4] = {mc.nd[k].x, mc.nd[k].y, 0.0, 1.0};
+      double p[3];
+      d_matmul<3, 4, 1>(pose, h, p);
+      Px[i] = p[0];
+      Py[i] = p[1];
+      Pz[i] = p[2];
+      flg[i] = (unsigned char)((p[2] < 0 ? 1 : 0) | (p[2] > -max_range ? 2 : 0));
+    }
+  }
+  __syncthreads();
+  TSTAMP(4);
+  int ff[K];  // flags of the two ends of edge slot k: flg[ed.x] | flg[ed.y] << 8 (0 for an empty slot)
+#pragma unroll
+  for (int k = 0; k < K; k++) ff[k] = k * TC_NT + tid < ne ? (int)flg[mc.ed[k].x] | ((int)flg[mc.ed[k].y] << 8) : 0;
+  // camera.py:71-74, 75-77 (plane z = -1e-7, flag idx_front), then 81-83, 84-86 (plane z = -max_range, flag
+  // idx_in_range): one copy of the pass, looped
+#pragma nounroll
+  for (int pass = 0; pass < 4 && !DBG_ON(a.dbg, DBG_SKIP_CLIP); pass++) {
+    const int bit = pass < 2 ? 1 : 2;
+    const bool target_e0 = (pass & 1) == 0;
+    const double tz = pass < 2 ? -0.0000001 : -max_range;
+    int sel = 0;  // bit k: slot k straddles the plane in the direction of this pass
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const bool fa = ff[k] & bit, fb = (ff[k] >> 8) & bit;
+      sel |= (target_e0 ? (!fa && fb) : (fa && !fb)) ? 1 << k : 0;
+    }
+    if (__ballot(sel != 0) != 0) {
+      int n = 0;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const bool s_k = (sel >> k) & 1;
+        const unsigned long long mk = __ballot(s_k);
+        if (s_k) {
+          const int j = n + wave_rank(mk);
+          const int t = target_e0 ? mc.ed[k].x : mc.ed[k].y, o = target_e0 ? mc.ed[k].y : mc.ed[k].x;
+          list[2 * j] = k * TC_NT + tid;
+          list[2 * j + 1] = t | (o << 16);
+        }
+        n += __popcll(mk);
+      }
+      __syncthreads();
+      // the usual case: every straddling edge has a target node of its own -> one move each, order irrelevant
+      bool dup = n > TC_NT;
+      int mine = 0;
+      if (tid < n && n <= TC_NT) {
+        mine = list[2 * tid + 1];
+        for (int j = 0; j < n; j++) dup |= j != tid && (list[2 * j + 1] & 0xffff) == (mine & 0xffff);
+      }
+      if (__ballot(dup) == 0) {
+        if (tid < n) {
+          const int t = mine & 0xffff, o = (unsigned)mine >> 16;
+          cam_move_to_plane(Px, Py, Pz, o, t, tz);
+          unsigned int f = flg[t] | (unsigned)bit;
+          if (pass < 2) f = (f & ~2u) | (Pz[t] > -max_range ? 2u : 0u);
+          flg[t] = (unsigned char)f;
+        }
+      } else {
+        cam_chain_replay(Px, Py, Pz, flg, bit, tz, list, n, max_range, pass < 2, tid);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < K; k++) ff[k] = k * TC_NT + tid < ne ? (int)flg[mc.ed[k].x] | ((int)flg[mc.ed[k].y] << 8) : 0;
+    }
+    if (pass < 3) TSTAMP(17 + pass);
+  }
+  TSTAMP(5);
+  // Only nodes in front AND in range can be "visible" (camera.py:92-93), and an edge is drawn when one of its ends is
+  // (camera.py:95) -- with the pixel coordinates of BOTH ends.  So the nodes worth projecting (two f64 divisions each)
+  // are the ends of edges that have an end in front and in range: mark them, compact them, project them in one
+  // lane-parallel pass.
+  int cand = 0;  // bit k: edge slot k has an end in front and in range
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int fa = ff[k] & 0xff, fb = ff[k] >> 8;
+    if ((fa & 3) == 3 || (fb & 3) == 3) {  // (lanes sharing a node write the same value: nothing else changes here)
+      cand |= 1 << k;
+      flg[mc.ed[k].x] = (unsigned char)(fa | 16);
+      flg[mc.ed[k].y] = (unsigned char)(fb | 16);
+    }
+  }
+  __syncthreads();
+  int ncand = 0;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int i = k * TC_NT + tid;
+    const bool c = i < nn && (flg[i] & 16);
+    const unsigned long long mk = __ballot(c);
+    if (c) list[ncand + wave_rank(mk)] = i;
+    ncand += __popcll(mk);
+  }
+  __syncthreads();
+  for (int k = tid; k < ncand; k += TC_NT) {  // camera.py:133-142, 90
+    const int i = list[k];
+    double u, v;
+    int2 q = cam_project(Kc, Px[i], Py[i], Pz[i], u, v);
+    const bool vis = (u > 0) && (u < cam.W) && (v > 0) && (v < cam.H) && (flg[i] & 3) == 3;
+    ((int2*)Px)[i] = q;  // renderer.py:43,50 np.int32(...)
+    if (vis) flg[i] |= 4;
+  }
+  __syncthreads();
+  TSTAMP(6);
+  // camera.py:95: the edges with a visible end, compacted first (edge id, end nodes) so that the code that emits a
+  // segment runs once over a dense list instead of once per register slot with a few lanes active in each
+  int ndraw = 0;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    bool draw = false;
+    if ((cand >> k) & 1) draw = ((flg[mc.ed[k].x] | flg[mc.ed[k].y]) & 4) != 0;  // a visible end
+    const unsigned long long mk = __ballot(draw);
+    if (draw) {
+      const int j = ndraw + wave_rank(mk);
+      list[2 * j] = k * TC_NT + tid;
+      list[2 * j + 1] = mc.ed[k].x | (mc.ed[k].y << 16);
+    }
+    ndraw += __popcll(mk);
+  }
+  __syncthreads();
+  for (int j = tid; j < ndraw; j += TC_NT) {  // both ends were marked above and hold pixel coordinates
+    const int e = list[2 * j], xy = list[2 * j + 1];
+    const int2 pa = ((int2*)Px)[xy & 0xffff], pb = ((int2*)Px)[(unsigned)xy >> 16];
+    int layer = l0;
+    for (int c = l0 + 1; c < l1; c++) layer += (ge0 + e) >= m.edge_off[c];
+    my_layers |= 1u << layer;
+    int* o = segg + 5 * (nseg + j);  // < seg_cap == total edge count
+    o[0] = layer;
+    o[1] = pa.x;
+    o[2] = pa.y;
+    o[3] = pb.x;
+    o[4] = pb.y;
+  }
+  nseg += ndraw;
+  __syncthreads();  // the next group reuses the node buffer
+}
+
 template <int K>
 __device__ inline void cam_fixup_pass(MapCache<K>& mc, const DevMap& m, bool reload, int ge0, int ne, int gn0, int nwin,
                                       double* Px, double* Py, double* Pz, unsigned char* flg, int bit, bool target_e0,
@@ -411,31 +627,7 @@ __device__ inline void cam_fixup_pass(MapCache<K>& mc, const DevMap& m, bool rel
     }
   }
   __syncthreads();
-  const int n = *cnt;
-  for (int k = tid; k < n; k += TC_NT) {
-    const int e = list[2 * k];
-    const int t = list[2 * k + 1] & 0xffff;
-    bool first = true;
-    for (int j = 0; j < n; j++)
-      if ((list[2 * j + 1] & 0xffff) == t && list[2 * j] < e) first = false;
-    if (!first) continue;
-    int cur = e, o = (unsigned)list[2 * k + 1] >> 16;  // the end that stays
-    for (int guard = 0; guard < n; guard++) {
-      cam_move_to_plane(Px, Py, Pz, o, t, tz);
-      int nxt = 0x7fffffff, no = 0;
-      for (int j = 0; j < n; j++) {
-        const int ej = list[2 * j], pj = list[2 * j + 1];
-        if ((pj & 0xffff) == t && ej > cur && ej < nxt) {
-          nxt = ej;
-          no = (unsigned)pj >> 16;
-        }
-      }
-      if (nxt == 0x7fffffff) break;
-      cur = nxt;
-      o = no;
-    }
-    flg[t] |= (unsigned char)bit;
-  }
+  cam_chain_replay(Px, Py, Pz, flg, bit, tz, list, *cnt, 0.0, false, tid);
   __syncthreads();
 }
 
@@ -736,7 +928,44 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
     // ---- phase B: lane-line distances (car.py:55-64)
     const int C = m.C;
     double dist_l = 0;  // lane l < C: distance to lane-line layer l (0 while the info is empty, car.py:47-51)
-    if (have_info && !(flags & DBG_SKIP_DIST)) {
+    if (have_info && !DBG_ON(flags, DBG_SKIP_DIST)) {
+      int my_e = -1;
+      const int cell = uni_i(d_grid_cell(m, s.x, s.y));  // (every lane holds the same state)
+      if (cell >= 0) {
+        // layer.py:43 over the cell's candidate edges (DevMap: every edge that can be the first minimum for a point of
+        // the cell, all layers, ascending): one lane per candidate, two distances straight from the edge record
+        const int o0 = m.cand_off[cell * C], o1 = m.cand_off[cell * C + C];
+        TSTAMP(14);
+        for (int l0 = 0; l0 < C; l0 += TC_AG) {
+          double bd[TC_AG];
+          int best[TC_AG], lo[TC_AG], hi[TC_AG];
+#pragma unroll
+          for (int g = 0; g < TC_AG; g++) {
+            bd[g] = 0;
+            best[g] = -1;
+            lo[g] = l0 + g < C ? m.edge_off[l0 + g] : 0x7fffffff;
+            hi[g] = l0 + g < C ? m.edge_off[l0 + g + 1] : 0x7fffffff;
+          }
+          const int e_lo = m.edge_off[l0], e_hi = m.edge_off[l0 + TC_AG < C ? l0 + TC_AG : C];
+          for (int i = o0 + tid; i < o1; i += TC_NT) {
+            const int e = m.cand_idx[i];
+            if (e >= e_lo && e < e_hi) {
+              const double4 q = m.edge_xy[e];
+              const double d = tc_fabs(d_dist(s.x, s.y, q.x, q.y) + d_dist(s.x, s.y, q.z, q.w));
+#pragma unroll
+              for (int g = 0; g < TC_AG; g++) {
+                const bool take = e >= lo[g] && e < hi[g] && (best[g] < 0 || d < bd[g]);
+                bd[g] = take ? d : bd[g];
+                best[g] = take ? e - lo[g] : best[g];
+              }
+            }
+          }
+          wave_argmin_group(bd, best);
+#pragma unroll
+          for (int g = 0; g < TC_AG; g++)
+            if (tid == l0 + g) my_e = best[g];
+        }
+      } else {
       for (int w = 0; w < nwin_n; w++) {
         if (!single) cache_nodes(mc, m, w * K * TC_NT, m.total_nodes, tid);
 #pragma unroll
@@ -747,7 +976,6 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
       }
       __syncthreads();
       TSTAMP(14);
-      int my_e = -1;
       // layer.py:43 for every layer: each lane scans its edges once (ascending index) and keeps one partial per layer
       // of the current group of TC_AG layers; the group's reductions then run together (wave_argmin_group).  A layer's
       // edges are contiguous, so edge e belongs to group layer g iff edge_off[l0 + g] <= e < edge_off[l0 + g + 1].
@@ -784,6 +1012,7 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
 #pragma unroll
         for (int g = 0; g < TC_AG; g++)
           if (tid == l0 + g) my_e = best[g];
+      }
       }
       TSTAMP(15);
       if (tid < C) {
@@ -851,8 +1080,24 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
 // (row `seg_row` of the per-env lists).  Depends on the env's state only through `fp`, so a frame can be produced by the
 // wavefront that simulated the step or by any other one later.  mc_loaded: `mc` already holds the whole map's window
 // (the simulate stage of the same wavefront loaded it).
+// camera.py:62 `pose = E @ car3d` of one frame: the 3x4 matrix every node of the map is transformed with.  It depends on
+// the env's state only through fp (and on the env's camera): the simulate stage computes it once per (step, env) and
+// hands it over in the pose row, so the 64 lanes of a frame wavefront do not each redo the two matrix products.
+#define TC_POSE_ROW 16  // doubles per (step, env) pose row: the 12 entries, padded to 128 bytes
+__device__ __forceinline__ void cam_pose12(const KArgs& a, int env, const FramePose& fp, double* pose) {
+  double Ec[12];  // this env's camera (camera.py:23-24,48-50): shared, or its own after tc_env_set_camera_per_env
+#pragma unroll
+  for (int i = 0; i < 12; i++) Ec[i] = a.cam_E ? a.cam_E[(size_t)env * 12 + i] : a.cam.E[i];
+  const double cth = fp.cth, sth = fp.sth;
+  double R[16] = {cth, -sth, 0, 0, sth, cth, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  double Tm[16] = {1, 0, 0, -fp.x, 0, 1, 0, -fp.y, 0, 0, 1, 0, 0, 0, 0, 1};
+  double car3d[16];
+  d_matmul<4, 4, 4>(R, Tm, car3d);
+  d_matmul<3, 4, 4>(Ec, car3d, pose);  // camera.py:62
+}
+
 template <int K>
-__device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, int env, const FramePose& fp, MapCache<K>& mc,
+__device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, int env, const double* pose_in, MapCache<K>& mc,
                                          const bool mc_loaded, const int tid, const int seg_row, int& nseg_out,
                                          unsigned int& used_out) {
   unsigned int my_layers = 0;  // layers this lane put a segment into the draw list for
@@ -871,22 +1116,11 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
   int* cnt = (int*)(smem + a.lds.off_cnt);
   const DevCam& cam = a.cam;
   double pose[12], Kc[9];
-  {
-    double Ec[12];  // this env's camera (camera.py:23-24,48-50): shared, or its own after tc_env_set_camera_per_env
 #pragma unroll
-    for (int i = 0; i < 12; i++) Ec[i] = a.cam_E ? a.cam_E[(size_t)env * 12 + i] : cam.E[i];
+  for (int i = 0; i < 9; i++) Kc[i] = a.cam_K ? a.cam_K[(size_t)env * 9 + i] : cam.K[i];
+  // the 12 entries are the same in every lane: kept in scalar registers through the node loop (24 VGPRs less)
 #pragma unroll
-    for (int i = 0; i < 9; i++) Kc[i] = a.cam_K ? a.cam_K[(size_t)env * 9 + i] : cam.K[i];
-    const double cth = fp.cth, sth = fp.sth;
-    double R[16] = {cth, -sth, 0, 0, sth, cth, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    double Tm[16] = {1, 0, 0, -fp.x, 0, 1, 0, -fp.y, 0, 0, 1, 0, 0, 0, 0, 1};
-    double car3d[16];
-    d_matmul<4, 4, 4>(R, Tm, car3d);
-    d_matmul<3, 4, 4>(Ec, car3d, pose);  // camera.py:62
-    // the 12 entries are the same in every lane: kept in scalar registers through the node loop (24 VGPRs less)
-#pragma unroll
-    for (int i = 0; i < 12; i++) pose[i] = uni_d(pose[i]);
-  }
+  for (int i = 0; i < 12; i++) pose[i] = uni_d(pose_in[i]);
   // The lane-line layers of a camera group are processed together: node ids are made global (edges_g) and then
   // relative to the group, so each of the passes below is ONE loop over the group's nodes / edges instead of one
   // per layer (the layers never share nodes, so camera.py's per-layer loop and this are the same computation).
@@ -896,7 +1130,7 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
   int* seg_cnt = cnt + 5;
   const size_t seg_slot = (size_t)seg_row * a.N + env;
   int* segg = a.seg_g + seg_slot * a.seg_cap * 5;  // [seg_cap][5]: layer, x0, y0, x1, y1
-  if (tid == 5) cnt[5] = 0;
+  int nseg = 0;  // draw-list length so far (wave-uniform)
   for (int g = 0; g < a.n_grp; g++) {
     const int l0 = a.grp_layer[g], l1 = a.grp_layer[g + 1];
     const int gn0 = m.node_off[l0], ge0 = m.edge_off[l0];
@@ -908,7 +1142,13 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
       cache_nodes(mc, m, gn0, gn0 + nn, tid);
       cache_edges(mc, m, ge0, ge0 + ne, gn0, tid);
     }
+    if (one) {
+      cam_group_regs<K>(a, mc, pose, Kc, l0, l1, ge0, nn, ne, Px, Py, Pz, flg, list, segg, nseg, my_layers, env, tid);
+      continue;
+    }
+    // a group larger than the register window (no bundled map): window by window, lists and counters in LDS
     if (tid < 5) cnt[tid] = 0;
+    if (tid == 5) cnt[5] = nseg;
     for (int w = 0; w < nwn; w++) {  // camera.py:124-131
       if (reload) cache_nodes(mc, m, gn0 + w * K * TC_NT, gn0 + nn, tid);
 #pragma unroll
@@ -930,7 +1170,7 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
     // camera.py:71-74, 75-77 (plane z = -1e-7, flag idx_front), then 81-83, 84-86 (plane z = -max_range, flag
     // idx_in_range): ONE inlined copy of the pass, looped -- four copies were ~4 k instructions of the kernel
 #pragma nounroll
-    for (int pass = 0; pass < 4; pass++) {
+    for (int pass = 0; pass < 4 && !DBG_ON(a.dbg, DBG_SKIP_CLIP); pass++) {
       if (pass == 2) {
         for (int i = tid; i < nn; i += TC_NT)
           if (Pz[i] > -cam.max_range) flg[i] |= 2;  // camera.py:80, on the mutated depths
@@ -1000,9 +1240,11 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
       }
     }
     __syncthreads();  // the next group reuses the node buffer and the counters
+    nseg = uni_i(*seg_cnt);
+    __syncthreads();
   }
   TSTAMP(7);
-  nseg_out = uni_i(*seg_cnt);
+  nseg_out = nseg;
   if (tid == 0) a.seg_n[seg_slot] = nseg_out;  // (for a raster launch of its own; the same wavefront gets it in a register)
   used_out = 0;
   for (int c = 0; c < m.C; c++)
@@ -1016,7 +1258,9 @@ struct MultiArgs {
                  // over all (step, env) frames behind this kernel; 1: row 0 every step (same wavefront rasterises it)
   int cam_here;  // tc_env_kernel: 1 = the camera stage (draw list) runs in this kernel, 0 = not (no observation wanted,
                  // or tc_frame_kernel produces the frames from pose_rows)
-  double* pose_rows;  // [nsteps][N][4] (x, y, cos(-theta), sin(-theta)) of every step for tc_frame_kernel, or NULL
+  double* pose_rows;  // [nsteps][N][TC_POSE_ROW] camera.py:62 pose matrix of every (step, env) for tc_frame_kernel, or NULL
+  int map_lds;        // tc_envg_kernel: 1 = the lane-line edge records (end points + orientations, 48 bytes per edge) are
+                      // copied into the workgroup's LDS at kernel start and phase B reads them from there
   tc_rollout roll;
 };
 __device__ __forceinline__ RollStep roll_at(const tc_rollout& r, size_t row0) {
@@ -1065,9 +1309,10 @@ struct RArgs {
 #define TC_RASTER_WAVES 4
 #endif
 template <bool THICK, int FMT>
-__device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem, int env, unsigned char* obs_base,
+__device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem, int env, unsigned char* obs_base,
                                             const int tid, const size_t seg_slot0, const int nseg_in,
                                             const unsigned int used_in, const int frame_row) {
+  const RArgs& a = a0;
   const RCam& cam = a.cam;
   unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
   const int* segg = a.seg_g + (seg_slot0 + env) * a.seg_cap * 5;
@@ -1111,7 +1356,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
     r.y0 = y0;
     r.y1 = y1;
     const int plane = cam.band_rows * wpr;
-    if (a.flags & DBG_SKIP_RASTER) {
+    if (DBG_ON(a.flags, DBG_SKIP_RASTER)) {
     } else if (!THICK) {
       for (int k = tid; k < nseg; k += TC_NT) {
         const int* sg = segg + 5 * k;
@@ -1123,6 +1368,10 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
       // Segments are taken RB at a time; their pixel work is cut into small uniform items that are dealt
       // to the 64 lanes through prefix sums, so one long line does not serialise the wave.
       for (int base = 0; base < nseg; base += RB) {
+        // (the loops usually run once: arguments are re-read inside them instead of being hoisted in front and held --
+        // or spilled -- across the whole stage)
+        const RArgs& a = kernarg_again(a0);
+        const RCam& cam = a.cam;
         const int nb = nseg - base < RB ? nseg - base : RB;
         if (tid < RB) {  // per segment: ThickLine's dp, fill walker pieces, fill rows of this band
           int nrow = 0, lo = 0, np = 0, wm = 0, dpx = 0, dpy = 0, okq = 0;
@@ -1141,14 +1390,14 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
               const long long ymin = (ya < yb ? ya : yb) - mg, ymax = (ya < yb ? yb : ya) + mg;
               touch = ymax >= y0 && ymin < y1;
             }
-            if (touch && !(a.flags & DBG_SKIP_QUAD) &&
+            if (touch && !DBG_ON(a.flags, DBG_SKIP_QUAD) &&
                 r_quad(sg[1], sg[2], sg[3], sg[4], cam.thickness, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3)) {
               TSTAMP(21);
               okq = 1;
               dpx = (int)(qx0 - (long long)sg[1] * TC_XY_ONE);
               dpy = (int)(qy0 - (long long)sg[2] * TC_XY_ONE);
               int hi = -1;
-              if (!(a.flags & DBG_SKIP_EVENTS))
+              if (!DBG_ON(a.flags, DBG_SKIP_EVENTS))
               np = r_fill_events(W, H, qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, fpy + 4 * tid, fpv + 4 * tid, wm, lo,
                                  hi);
               TSTAMP(22);
@@ -1181,7 +1430,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
             const bool a_minus = e == 2 || e == 3, b_minus = e == 1 || e == 2;
             long long ax = (a_is_p1 ? p1x : p0x) + (a_minus ? -dpx : dpx), ay = (a_is_p1 ? p1y : p0y) + (a_minus ? -dpy : dpy);
             long long bx = (b_is_p1 ? p1x : p0x) + (b_minus ? -dpx : dpx), by = (b_is_p1 ? p1y : p0y) + (b_minus ? -dpy : dpy);
-            if (e < (fm[j] & 0xff) && !(a.flags & DBG_SKIP_SLOPE)) {  // fill piece e of this segment: x at its start row and slope
+            if (e < (fm[j] & 0xff) && !DBG_ON(a.flags, DBG_SKIP_SLOPE)) {  // fill piece e of this segment: x at its start row and slope
               long long xs, dxs;
               r_fill_slope(qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3, fpy[t], fpv[t], xs, dxs);
               fpx[t] = xs;
@@ -1189,7 +1438,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
             }
             LineP L;
             L.ecount = -1;
-            if (!(a.flags & DBG_SKIP_LINESETUP)) L = r_line2_setup(W, H, ax, ay, bx, by);
+            if (!DBG_ON(a.flags, DBG_SKIP_LINESETUP)) L = r_line2_setup(W, H, ax, ay, bx, by);
             if (L.ecount >= 0) {
               r.bits = bits + sg[0] * plane;
               r_put(r, L.ex, L.ey);
@@ -1219,7 +1468,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
         }
         __syncthreads();
         TSTAMP(11);
-        for (int c = tid; c < tot_l && !(a.flags & DBG_SKIP_R2); c += TC_NT) {  // outline pixels, LCH steps per chunk
+        for (int c = tid; c < tot_l && !DBG_ON(a.flags, DBG_SKIP_R2); c += TC_NT) {  // outline pixels, LCH steps per chunk
           int lo = 0, hi = RB * 4;
           while (hi - lo > 1) {
             int mid = (lo + hi) >> 1;
@@ -1232,7 +1481,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
           r.bits = bits + o[4] * plane;
           r_line2_pixels(r, o[0], o[1], o[2], xmajor, k0, k1);
         }
-        for (int c = tid; c < tot_f && !(a.flags & DBG_SKIP_R3); c += TC_NT) {  // scanline fill, one row per item
+        for (int c = tid; c < tot_f && !DBG_ON(a.flags, DBG_SKIP_R3); c += TC_NT) {  // scanline fill, one row per item
           int lo = 0, hi = RB;
           while (hi - lo > 1) {
             int mid = (lo + hi) >> 1;
@@ -1243,7 +1492,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
           r.bits = bits + segg[5 * (base + lo)] * plane;
           r_fill_row(r, row, mm & 0xff, (mm >> 8) & 0xff, fpy + 4 * lo, fpx + 4 * lo, fpd + 4 * lo);
         }
-        for (int t = tid; t < nb * 2 && !(a.flags & DBG_SKIP_R4); t += TC_NT) {  // round caps (flags = 3: both ends)
+        for (int t = tid; t < nb * 2 && !DBG_ON(a.flags, DBG_SKIP_R4); t += TC_NT) {  // round caps (flags = 3: both ends)
           const int k = base + (t >> 1);
           const int* sg = segg + 5 * k;
           r.bits = bits + sg[0] * plane;
@@ -1326,7 +1575,9 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
       used_layers = C >= 32 ? 0xffffffffu : ((1u << C) - 1u);  // a copy may have filled a plane that had no segment
     }
     TSTAMP(12);
-    if (a.flags & DBG_SKIP_STORE) {
+    const RArgs& a = kernarg_again(a0);
+    const RCam& cam = a.cam;
+    if (DBG_ON(a.flags, DBG_SKIP_STORE)) {
     } else if (FMT == TC_FMT_CLASSES) {
       if ((W & 15) == 0) {
         // 16 pixels -> one 16-byte store per lane, consecutive lanes on consecutive addresses
@@ -1449,8 +1700,11 @@ __device__ __forceinline__ void raster_body(const RArgs& a, unsigned char* smem,
 }
 
 template <bool THICK, int FMT>
-__global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs a) {
+__global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs a_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // raster_body re-reads its arguments through kernarg_again(): it must be handed the block in the kernarg segment
+  // itself, not a by-value copy the compiler is free to keep in registers or scratch
+  const RArgs& a = *(const RArgs*)(const __attribute__((address_space(4))) RArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   const int env = a.env0 + blockIdx.x;
   if (env >= a.N) return;
   if (a.mask && !a.mask[env]) return;
@@ -1709,18 +1963,22 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) vo
     FramePose fp;
     sim_body<K>(sa.a, smem, env, sa.mode, (const char*)sa.car_control + row0 * 2 * esz, sa.cdtype, sa.maneuver + row0,
                 sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), tid, mc, fp);
-    if (sa.ma.pose_rows && tid < 4) {
-      double v = fp.x;
-      v = tid == 1 ? fp.y : v;
-      v = tid == 2 ? fp.cth : v;
-      v = tid == 3 ? fp.sth : v;
-      step_args().ma.pose_rows[(row0 + env) * 4 + tid] = v;
+    if (sa.ma.pose_rows) {
+      double pose[12];
+      cam_pose12(sa.a, env, fp, pose);
+      if (tid == 0) {
+        double2* o = (double2*)(step_args().ma.pose_rows + (row0 + env) * TC_POSE_ROW);
+#pragma unroll
+        for (int i = 0; i < 6; i++) o[i] = make_double2(pose[2 * i], pose[2 * i + 1]);
+      }
     }
     if (CAM && sa.ma.cam_here) {
       if (wants_frame(sa)) {
         int nseg;
         unsigned int used;
-        cam_body<K>(sa.a, smem, env, fp, mc, sa.mode != MODE_RENDER, tid, seg_row, nseg, used);  // (tc_render skips phase B's fetch)
+        double pose[12];
+        cam_pose12(sa.a, env, fp, pose);
+        cam_body<K>(sa.a, smem, env, pose, mc, sa.mode != MODE_RENDER, tid, seg_row, nseg, used);  // (tc_render skips phase B's fetch)
       }
       else if (tid == 0)
         step_args().a.seg_n[(size_t)seg_row * sa.a.N + env] = 0;
@@ -1745,13 +2003,21 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) vo
 // The price is latency (a group of 8 lanes walks 33 edges per layer pass one after the other), which nobody waits for:
 // the kernel leaves most of the chip's issue slots free for the frame kernel of the previous call.
 #define TC_EL 8
+#define TC_ENVG_NT 256  // threads per workgroup: 4 wavefronts = 32 envs share one LDS copy of the edge records
 struct GroupLds {  // per env of the wavefront: what the reward / termination terms read and count
   double dist[TC_MAX_LAYERS];
   int cnt[TC_MAX_TERMS];
 };
 
-__global__ __launch_bounds__(TC_NT) void tc_envg_kernel(StepArgs sa_unused) {
-  __shared__ GroupLds glds[TC_NT / TC_EL];
+// Where the edge records are read from matters when the kernel runs beside the frame kernel: a frame wavefront ends
+// with ~20 KB of 16-byte stores, and a global load of this kernel issued on the same CU queues behind those bursts in
+// the CU's vector-memory pipeline (measured: 22 us per step alone, 35 us beside the frame kernel, 23 us beside a frame
+// kernel with its stores switched off).  The edge scan is ~33 loads per lane and step: from LDS it neither waits for
+// the stores nor pays an L2 round trip per batch of loads.
+typedef const __attribute__((address_space(3))) double* LdsDouble;
+__global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused) {
+  __shared__ GroupLds glds[TC_ENVG_NT / TC_EL];
+  extern __shared__ __align__(16) unsigned char gsm[];
   // Highest issue priority: when this kernel shares the chip with the frame kernel of the previous chunk it is the
   // critical path (a serial chain per step, few instructions), and the frame wavefronts would otherwise crowd it out
   // of the vector issue slots by sheer number (measured: 36 us per step beside them, 21 us alone).
@@ -1759,7 +2025,26 @@ __global__ __launch_bounds__(TC_NT) void tc_envg_kernel(StepArgs sa_unused) {
   const StepArgs& s0 = step_args();
   const int lane = threadIdx.x, sub = lane & (TC_EL - 1), grp = lane / TC_EL;
   const int N = s0.a.N;
-  int env = s0.a.env0 + blockIdx.x * (TC_NT / TC_EL) + grp;
+  int env = s0.a.env0 + blockIdx.x * (TC_ENVG_NT / TC_EL) + grp;
+  const bool map_lds = s0.ma.map_lds != 0;
+  const LdsDouble l_exy = (LdsDouble)gsm;  // [total_edges][4]: n0.x, n0.y, n1.x, n1.y
+  const LdsDouble l_ofw = (LdsDouble)(gsm + (size_t)s0.a.m.total_edges * 32);
+  const LdsDouble l_orv = l_ofw + s0.a.m.total_edges;
+  if (map_lds) {
+    const DevMap& m0 = s0.a.m;
+    __attribute__((address_space(3))) double* w4 = (__attribute__((address_space(3))) double*)gsm;
+    __attribute__((address_space(3))) double* wd = w4 + (size_t)m0.total_edges * 4;
+    for (int i = lane; i < m0.total_edges; i += TC_ENVG_NT) {
+      const double4 q = m0.edge_xy[i];
+      w4[4 * i] = q.x;
+      w4[4 * i + 1] = q.y;
+      w4[4 * i + 2] = q.z;
+      w4[4 * i + 3] = q.w;
+      wd[i] = m0.ori_fwd[i];
+      wd[m0.total_edges + i] = m0.ori_rev[i];
+    }
+    __syncthreads();
+  }
   const bool live = env < N;  // groups past the last env compute on a copy of it and store nothing
   env = live ? env : N - 1;
   GroupLds& gl = glds[grp];
@@ -1803,6 +2088,7 @@ __global__ __launch_bounds__(TC_NT) void tc_envg_kernel(StepArgs sa_unused) {
     const RollStep roll = roll_at(sa.ma.roll, row0);
     status = 0;
     trunc = 0;
+    TSTAMP(24);
     PathInfo pinfo;
     pinfo.ax = pinfo.ay = pinfo.bx = pinfo.by = pinfo.ori = 0;
     pinfo.valid = 0;
@@ -1837,10 +2123,13 @@ __global__ __launch_bounds__(TC_NT) void tc_envg_kernel(StepArgs sa_unused) {
       v = d_np_clip(v, -1.0, 1.0);  // env.py:118
       st = d_np_clip(st, -1.0, 1.0);
       const int man = sa.maneuver[row0 + env];
+      TSTAMP(25);
       d_car_kinematics(a.car, s, v, st, have_trig);
+      TSTAMP(26);
       trunc = d_find_local_path<TC_EL>(m, s, man, status, pinfo, sub);
       have_trig = true;
     }
+    TSTAMP(27);
     // ---- info (car.py:46-53), default reward / termination (env.py:93,99)
     const bool have_info = !fresh && s.lp_len >= 2;
     cte = 0;
@@ -1867,46 +2156,107 @@ __global__ __launch_bounds__(TC_NT) void tc_envg_kernel(StepArgs sa_unused) {
     // ---- phase B: nearest lane-line edge and distance per layer (car.py:55-64, layer.py:33-44,126-164)
     const int C = m.C;
     const bool last = k == nsteps - 1;
-    for (int l = 0; l < C; l++) {
-      double dist_l = 0;
-      int ne = -1;
-      if (have_info) {
-        const int eo = m.edge_off[l], eend = m.edge_off[l + 1];
-        double bd = 0;
-        int best = -1;
-#pragma unroll 4
-        for (int e = eo + sub; e < eend; e += TC_EL) {  // this lane's edges of the layer, ascending (layer.py:43)
-          const double4 q = m.edge_xy[e];  // both end points: independent loads, several in flight
-          const double d = tc_fabs(d_dist(s.x, s.y, q.x, q.y) + d_dist(s.x, s.y, q.z, q.w));
-          if (best < 0 || d < bd) {
-            best = e - eo;
-            bd = d;
+    const int cell = have_info ? d_grid_cell(m, s.x, s.y) : -1;
+    TSTAMP(0);
+    static_assert(TC_EL == 8 && TC_AG <= TC_EL, "group8_argmin_multi, one lane per layer of a block");
+    if (have_info) {
+      // The cell's candidate edges (DevMap: every edge that can be the first minimum for a point of the cell, layer by
+      // layer, ascending -- a handful per layer), a block of TC_AG layers at a time.  Memory first, arithmetic after: the
+      // block's list offsets are fetched together, then each lane's first candidate of every layer together (two load
+      // latencies for the whole block, whatever the vector-memory pipeline's queue looks like beside the frame kernel),
+      // then the layers are scanned one after the other from the LDS edge records; lane g of the group finally evaluates
+      // layer g's tail, so the bounds test and the distance run once per block, not once per layer.
+      //   A car outside the grid (cell < 0) runs the SAME code with the identity list -- every edge of the layer -- so a
+      // wavefront with one such env executes longer loops, not a second copy of the phase.
+      const bool far = cell < 0;
+      for (int lb = 0; lb < C; lb += TC_AG) {
+        double bd[TC_AG];
+        int best[TC_AG], lo[TC_AG], off[TC_AG + 1], e0[TC_AG];
+#pragma unroll
+        for (int g = 0; g <= TC_AG; g++) {
+          const int lg = lb + g < C ? lb + g : C;
+          off[g] = far ? m.edge_off[lg] : m.cand_off[cell * C + lg];
+        }
+#pragma unroll
+        for (int g = 0; g < TC_AG; g++) {
+          lo[g] = lb + g < C ? m.edge_off[lb + g] : 0;
+          e0[g] = off[g] + sub < off[g + 1] ? (far ? off[g] + sub : m.cand_idx[off[g] + sub]) : -1;
+        }
+#pragma unroll
+        for (int g = 0; g < TC_AG; g++) {
+          double bdg = 0;
+          int bg = -1, e = e0[g];
+          for (int i = off[g] + sub; i < off[g + 1]; i += TC_EL) {
+            double4 q;
+            if (map_lds)
+              q = make_double4(l_exy[4 * e], l_exy[4 * e + 1], l_exy[4 * e + 2], l_exy[4 * e + 3]);
+            else
+              q = m.edge_xy[e];
+            const double d = tc_fabs(d_dist(s.x, s.y, q.x, q.y) + d_dist(s.x, s.y, q.z, q.w));
+            if (bg < 0 || d < bdg) {
+              bg = e - lo[g];
+              bdg = d;
+            }
+            if (i + TC_EL < off[g + 1]) e = far ? i + TC_EL : m.cand_idx[i + TC_EL];
+          }
+          bd[g] = bdg;
+          best[g] = bg;
+        }
+        if (lb == 0) TSTAMP(16);
+        group8_argmin_multi(bd, best);
+        if (lb == 0) TSTAMP(1);
+        int ne = -1, eo = 0;
+#pragma unroll
+        for (int g = 0; g < TC_AG; g++) {
+          ne = sub == g ? best[g] : ne;
+          eo = sub == g ? lo[g] : eo;
+        }
+        const int l = lb + sub;
+        if (sub < TC_AG && l < C) {  // lane g: layer lb + g
+          double dist_l = 0;
+          if (ne >= 0) {
+            const int ge = eo + ne;
+            double4 q;
+            double o_fw, o_rv;
+            if (map_lds) {
+              q = make_double4(l_exy[4 * ge], l_exy[4 * ge + 1], l_exy[4 * ge + 2], l_exy[4 * ge + 3]);
+              o_fw = l_ofw[ge];
+              o_rv = l_orv[ge];
+            } else {
+              q = m.edge_xy[ge];
+              o_fw = m.ori_fwd[ge];
+              o_rv = m.ori_rev[ge];
+            }
+            const double2 n0 = make_double2(q.x, q.y), n1 = make_double2(q.z, q.w);
+            bool certain;
+            bool inb = d_within_bounds_filter(n0.x, n0.y, n1.x, n1.y, s.x, s.y, certain);
+            if (!certain) inb = d_within_bounds(n0.x, n0.y, n1.x, n1.y, o_fw, o_rv, s.x, s.y);
+            if (inb) {
+              dist_l = tc_fabs(d_distance_to_edge(n0.x, n0.y, n1.x, n1.y, s.x, s.y));
+            } else {
+              const double da = d_dist(s.x, s.y, n0.x, n0.y);
+              const double db = d_dist(s.front_x, s.front_y, n1.x, n1.y);  // FRONT axle for n1 (car.py:64)
+              dist_l = db < da ? db : da;
+            }
+          }
+          gl.dist[l] = dist_l;
+          if (last && live) {
+            b.laneline_distances[(size_t)env * C + l] = dist_l;
+            b.nearest_edge[(size_t)env * C + l] = ne;
           }
         }
-        group_argmin<TC_EL>(bd, best);
-        ne = best;
-        if (ne >= 0) {
-          const int ge = eo + ne;
-          const double4 q = m.edge_xy[ge];
-          const double2 n0 = make_double2(q.x, q.y), n1 = make_double2(q.z, q.w);
-          bool certain;
-          bool inb = d_within_bounds_filter(n0.x, n0.y, n1.x, n1.y, s.x, s.y, certain);
-          if (!certain) inb = d_within_bounds(n0.x, n0.y, n1.x, n1.y, m.ori_fwd[ge], m.ori_rev[ge], s.x, s.y);
-          if (inb) {
-            dist_l = tc_fabs(d_distance_to_edge(n0.x, n0.y, n1.x, n1.y, s.x, s.y));
-          } else {
-            const double da = d_dist(s.x, s.y, n0.x, n0.y);
-            const double db = d_dist(s.front_x, s.front_y, n1.x, n1.y);  // FRONT axle for n1 (car.py:64)
-            dist_l = db < da ? db : da;
-          }
-        }
+        if (lb == 0) TSTAMP(2);
       }
-      gl.dist[l] = dist_l;  // (every lane of the group writes the same value)
-      if (last && live && sub == 0) {
-        b.laneline_distances[(size_t)env * C + l] = dist_l;
-        b.nearest_edge[(size_t)env * C + l] = ne;
+    } else {
+      for (int l = sub; l < C; l += TC_EL) {  // no info this step (car.py:47-51): zero distances, no nearest edge
+        gl.dist[l] = 0;
+        if (last && live) {
+          b.laneline_distances[(size_t)env * C + l] = 0;
+          b.nearest_edge[(size_t)env * C + l] = -1;
+        }
       }
     }
+    TSTAMP(14);
     // ---- reward / termination wrappers (a re-spawned env did not go through Wrapper.step)
     if (a.n_terms > 0 && !fresh)
       d_apply_terms_mem(a.terms, a.n_terms, gl.cnt, a.car.track_width, C, cte, have_info ? s.velocity : 0.0, gl.dist, reward,
@@ -1920,13 +2270,23 @@ __global__ __launch_bounds__(TC_NT) void tc_envg_kernel(StepArgs sa_unused) {
       if (roll.reward) roll.reward[env] = reward;
       if (roll.terminated) roll.terminated[env] = (unsigned char)terminated;
     }
-    if (sa.ma.pose_rows && live && sub < 4) {
-      double pv = s.x;
-      pv = sub == 1 ? s.y : pv;
-      pv = sub == 2 ? (have_trig ? s.cth : tc_cos(-s.theta)) : pv;
-      pv = sub == 3 ? (have_trig ? -s.sth : tc_sin(-s.theta)) : pv;
-      sa.ma.pose_rows[(row0 + env) * 4 + sub] = pv;
+    if (sa.ma.pose_rows) {
+      // car.py:159-165 takes cos(-theta), sin(-theta): tc_cos is exactly even and tc_sin exactly odd, so the values of
+      // the front-axle update are reused bit for bit (as in sim_body)
+      FramePose fp;
+      fp.x = s.x;
+      fp.y = s.y;
+      fp.cth = have_trig ? s.cth : tc_cos(-s.theta);
+      fp.sth = have_trig ? -s.sth : tc_sin(-s.theta);
+      double pose[12];
+      cam_pose12(sa.a, live ? env : 0, fp, pose);
+      if (live && sub == 0) {
+        double2* o = (double2*)(sa.ma.pose_rows + (row0 + env) * TC_POSE_ROW);
+#pragma unroll
+        for (int i = 0; i < 6; i++) o[i] = make_double2(pose[2 * i], pose[2 * i + 1]);
+      }
     }
+    TSTAMP(15);
   }
   // ---- state and the last step's outputs back to the caller's buffers
   const StepArgs& s1 = step_args();
@@ -1963,28 +2323,42 @@ __global__ __launch_bounds__(TC_NT) void tc_envg_kernel(StepArgs sa_unused) {
 struct FrameArgs {
   KArgs a;
   RArgs r;
-  const double* pose_rows;  // [rows][N][4]
+  const double* pose_rows;  // [rows][N][TC_POSE_ROW]
 };
+// The argument block is read through a pointer the compiler cannot see through, once per stage: the stage's values are
+// then loaded (s_load from the kernarg segment) where they are used instead of all being fetched at kernel entry and
+// kept in -- or spilled from -- scalar registers across both stages.
+typedef const __attribute__((address_space(4))) FrameArgs* FrameArgsConst;
+__device__ __forceinline__ const FrameArgs& frame_args() {
+  unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const FrameArgs*)(FrameArgsConst)p;
+}
 template <int K, bool THICK, int FMT>
-__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame_kernel(FrameArgs fa) {
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame_kernel(FrameArgs fa_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
+  const FrameArgs& fa = frame_args();
   const int env = fa.a.env0 + blockIdx.x;
   if (env >= fa.a.N) return;
   const int tid = threadIdx.x;
   const int row = fa.r.seg_row0 + blockIdx.y;
   const size_t slot0 = (size_t)row * fa.a.N;
-  const double* pr = fa.pose_rows + (slot0 + env) * 4;
-  FramePose fp;
-  fp.x = pr[0];
-  fp.y = pr[1];
-  fp.cth = pr[2];
-  fp.sth = pr[3];
+  // the pose row the simulate launch wrote for this (step, env): one address for the whole wavefront, read through the
+  // scalar cache (written by an earlier launch: complete and visible before this kernel started)
+  const __attribute__((address_space(4))) double* pr =
+      (const __attribute__((address_space(4))) double*)(unsigned long long)(fa.pose_rows + (slot0 + env) * TC_POSE_ROW);
+  double pose[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) pose[i] = pr[i];
   MapCache<K> mc;
   int nseg;
   unsigned int used;
-  cam_body<K>(fa.a, smem, env, fp, mc, false, tid, row, nseg, used);
+  TSTAMP(3);
+  TSTAMP_REAL(30);
+  cam_body<K>(fa.a, smem, env, pose, mc, false, tid, row, nseg, used);
   __syncthreads();  // draw list written by this wavefront is visible to it (vmcnt(0) + barrier)
-  raster_body<THICK, FMT>(fa.r, smem, env, fa.r.obs + (size_t)blockIdx.y * fa.r.obs_row_stride, tid, slot0, nseg, used, row);
+  const FrameArgs& fr = frame_args();
+  raster_body<THICK, FMT>(fr.r, smem, env, fr.r.obs + (size_t)blockIdx.y * fr.r.obs_row_stride, tid, slot0, nseg, used, row);
 }
 
 // All stages in one launch: the same wavefront simulates its env, runs the camera and rasterises the frame.  The form
@@ -2018,7 +2392,9 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
     if (wants_frame(sa)) {
       int nseg;
       unsigned int used;
-      cam_body<K>(sa.a, smem, env, fp, mc, sa.mode != MODE_RENDER, tid, 0, nseg, used);  // (tc_render skips phase B's fetch)
+      double pose[12];
+      cam_pose12(sa.a, env, fp, pose);
+      cam_body<K>(sa.a, smem, env, pose, mc, sa.mode != MODE_RENDER, tid, 0, nseg, used);  // (tc_render skips phase B's fetch)
       __syncthreads();  // draw list written by this wavefront is visible to it (vmcnt(0) + barrier)
       const StepArgs& sb = step_args();
       const size_t obs_step = sb.ma.roll.obs ? (size_t)sb.a.N * ((size_t)sb.r.cam.H * sb.r.cam.W * (FMT == TC_FMT_CLASSES ? sb.r.C : 3)) : 0;
@@ -2104,9 +2480,10 @@ struct tc_env {
   hipStream_t frame_stream;
   hipEvent_t sim_ev, frames_ev;
   int prof_piped[TC_PROF_RING];
+  int envg_map_lds; // tc_envg_kernel keeps the edge records in LDS when they fit (TC_ENVG_MAP_LDS=0: always from global)
   int env_grouped;  // K-step calls: simulate with tc_envg_kernel (TC_EL lanes per env); TC_ENV_GROUPED=0 keeps one wavefront per env
   int *segm_g, *segm_n;  // [segm_rows][N][seg_cap][5], [segm_rows][N]
-  double* pose_rows;     // [segm_rows][N][4]
+  double* pose_rows;     // [segm_rows][N][TC_POSE_ROW]
   int segm_rows;
   int kvar;  // register-cache slots of the simulate stage: 5, 8 (whole map in one window), 9 (camera layer groups), 13
   hipStream_t side[TC_MAX_SPLIT];
@@ -2264,13 +2641,69 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
     delete m;
     return TC_E_INVALID;
   }
+  // ---- candidate grid (see DevMap): cells of >= 4 cm, at most ~64 k of them, over the lane lines + 4 m
+  std::vector<int> coff(1, 0), cidx;
+  {
+    bool finite = TN > 0 && TE > 0;
+    double bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+    for (int i = 0; i < TN && finite; i++) {
+      const double x = nodes[i].x, y = nodes[i].y;
+      if (!(fabs(x) < 1e12) || !(fabs(y) < 1e12)) finite = false;
+      if (i == 0 || x < bx0) bx0 = x;
+      if (i == 0 || x > bx1) bx1 = x;
+      if (i == 0 || y < by0) by0 = y;
+      if (i == 0 || y > by1) by1 = y;
+    }
+    if (const char* g = getenv("TC_CAND_GRID")) finite = finite && atoi(g) != 0;
+    std::vector<double> f(d.max_edges > 0 ? d.max_edges : 1);
+    // appends the lists of an nx x ny grid of `cell`-sized cells with origin (x0, y0); returns the id of its first cell
+    auto add_level = [&](double x0, double y0, double cell, int nx, int ny) {
+      const int base = (int)((coff.size() - 1) / C);
+      const double r = 0.5 * sqrt(2.0) * cell * 1.001 + 1e-12;
+      coff.resize(coff.size() + (size_t)nx * ny * C, 0);
+      for (int iy = 0; iy < ny; iy++)
+        for (int ix = 0; ix < nx; ix++) {
+          const double cx = x0 + (ix + 0.5) * cell, cy = y0 + (iy + 0.5) * cell;
+          for (int l = 0; l < C; l++) {
+            const int e0 = d.edge_off[l], e1 = d.edge_off[l + 1];
+            double fmin = 0;
+            for (int e = e0; e < e1; e++) {
+              const double4 q = exy[e];
+              const double a0 = q.x - cx, a1 = q.y - cy, b0 = q.z - cx, b1 = q.w - cy;
+              f[e - e0] = sqrt(a0 * a0 + a1 * a1) + sqrt(b0 * b0 + b1 * b1);
+              if (e == e0 || f[e - e0] < fmin) fmin = f[e - e0];
+            }
+            const double thr = fmin + 4.0 * r + 1e-9 * (1.0 + fmin);
+            for (int e = e0; e < e1; e++)
+              if (f[e - e0] <= thr) cidx.push_back(e);
+            coff[((size_t)base + (size_t)iy * nx + ix) * C + l + 1] = (int)cidx.size();
+          }
+        }
+      return base;
+    };
+    if (finite) {
+      const double margin = 4.0, x0 = bx0 - margin, y0 = by0 - margin, x1 = bx1 + margin, y1 = by1 + margin;
+      double cell = sqrt((x1 - x0) * (y1 - y0) / 65536.0);
+      if (cell < 0.04) cell = 0.04;
+      const int nx = (int)ceil((x1 - x0) / cell), ny = (int)ceil((y1 - y0) / cell);
+      if (nx >= 1 && ny >= 1 && (long long)nx * ny <= 200000) {
+        add_level(x0, y0, cell, nx, ny);
+        d.grid_nx = nx;
+        d.grid_ny = ny;
+        d.grid_x0 = x0;
+        d.grid_y0 = y0;
+        d.grid_inv = 1.0 / cell;
+      }
+    }
+    if (cidx.empty()) cidx.push_back(0);
+  }
   int rc = TC_OK;
   HIP_TRY(hipGetDevice(&m->device));
 #define UP(vec, field)                                             \
   if (rc == TC_OK) rc = upload(m, vec, &d.field);
   UP(fat, lp_fat) UP(nodes, nodes) UP(edges, edges) UP(edges_g, edges_g) UP(edge_layer, edge_layer) UP(of, ori_fwd) UP(orv, ori_rev) UP(exy, edge_xy) UP(lpn, lp_nodes) UP(lpe, lp_edges)
   UP(lpo, lp_ori) UP(noff, next_off) UP(nnode, next_node) UP(nori, next_ori) UP(poff, prev_off)
-  UP(pnode, prev_node) UP(pori, prev_ori)
+  UP(pnode, prev_node) UP(pori, prev_ori) UP(coff, cand_off) UP(cidx, cand_idx)
 #undef UP
   if (rc != TC_OK) {
     tc_map_destroy(m);
@@ -2320,6 +2753,8 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   if (const char* ms = getenv("TC_MULTI_SPLIT")) e->multi_split = atoi(ms) != 0;
   e->env_grouped = 1;
   if (const char* eg = getenv("TC_ENV_GROUPED")) e->env_grouped = atoi(eg) != 0;
+  e->envg_map_lds = 1;
+  if (const char* ml = getenv("TC_ENVG_MAP_LDS")) e->envg_map_lds = atoi(ml) != 0;
   e->chunk = 16;
   if (const char* ch = getenv("TC_CHUNK")) e->chunk = atoi(ch) > 0 ? atoi(ch) : 0;
   e->frame_stream = nullptr;
@@ -2961,7 +3396,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       void *p = nullptr, *q = nullptr, *pr = nullptr;
       hipError_t he = hipMalloc(&p, (size_t)nsteps * N * e->k.seg_cap * 5 * sizeof(int));
       if (he == hipSuccess) he = hipMalloc(&q, (size_t)nsteps * N * sizeof(int));
-      if (he == hipSuccess) he = hipMalloc(&pr, (size_t)nsteps * N * 4 * sizeof(double));
+      if (he == hipSuccess) he = hipMalloc(&pr, (size_t)nsteps * N * TC_POSE_ROW * sizeof(double));
       if (he != hipSuccess) {
         if (p) (void)hipFree(p);
         if (q) (void)hipFree(q);
@@ -3009,7 +3444,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       sa.ma.nsteps = cn;
       sa.ma.seg_rows = cn > 1 ? cn : 2;  // (> 1: row k of the chunk's lists; a one-step chunk still writes row 0 of them)
       sa.ma.cam_here = frames ? 0 : 1;
-      sa.ma.pose_rows = frames ? e->pose_rows + r0 * 4 : nullptr;
+      sa.ma.pose_rows = frames ? e->pose_rows + r0 * TC_POSE_ROW : nullptr;
       if (roll) {
         sa.ma.roll.obs = roll->obs ? roll->obs + r0 * (size_t)e->obs_bytes : nullptr;
         sa.ma.roll.reward = roll->reward ? roll->reward + r0 : nullptr;
@@ -3025,8 +3460,12 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       sa.maneuver = man + r0;
       sa.spawn_nodes = spawn;
       sa.mask = mask;
-      if (frames && e->env_grouped)
-        hipLaunchKernelGGL(tc_envg_kernel, dim3((N + TC_NT / TC_EL - 1) / (TC_NT / TC_EL)), dim3(TC_NT), 0, main, sa);
+      if (frames && e->env_grouped) {
+        const size_t map_bytes = (size_t)e->k.m.total_edges * 48;
+        sa.ma.map_lds = (e->envg_map_lds && map_bytes <= 40 * 1024) ? 1 : 0;
+        hipLaunchKernelGGL(tc_envg_kernel, dim3((N + TC_ENVG_NT / TC_EL - 1) / (TC_ENVG_NT / TC_EL)), dim3(TC_ENVG_NT),
+                           sa.ma.map_lds ? (map_bytes + 15) / 16 * 16 : 0, main, sa);
+      }
       else
         hipLaunchKernelGGL(frames ? kern_nocam : kern, dim3(N), dim3(TC_NT), e->k.lds.total, main, sa);
       HIP_TRY(hipGetLastError());
@@ -3053,6 +3492,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
           FrameArgs fa;
           memset(&fa, 0, sizeof(fa));
           fa.a = e->k;
+          fa.a.dbg = flags;
           fa.a.env0 = 0;
           fa.a.seg_g = e->segm_g;
           fa.a.seg_n = e->segm_n;

@@ -47,6 +47,12 @@ def main():
     ap.add_argument("--multi", type=int, default=0,
                     help="issue the steps through tc_step_multi, this many per launch (the stamps kept are those of the "
                          "LAST step of a launch: a wavefront that has been running with desynchronised neighbours)")
+    ap.add_argument("--envg", action="store_true",
+                    help="with --multi: the probes of tc_envg_kernel (one env per workgroup is stamped): top of step, "
+                         "action loaded, kinematics done, tracking done, phase B done, rollout rows written")
+    ap.add_argument("--frame", action="store_true",
+                    help="with --multi: the probes of tc_frame_kernel only (camera + raster of one frame per wavefront; "
+                         "the stamps kept per env are those of the frame that finished last)")
     a = ap.parse_args()
     mp, res = ("simple_layout", [64, 64]) if a.workload == "cfg3" else ("knuffingen", [128, 128])
     path = bundled_config(f"config_{mp}.yaml")
@@ -77,7 +83,9 @@ def main():
                     cc_all, mn_all = bench.gen_actions(N, K * (a.steps + 10), seed=0, device=torch.device("cuda:0"))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                env.step_multi(cc_all[t * K:(t + 1) * K], mn_all[t * K:(t + 1) * K])
+                if a.envg and t == 0:
+                    roll_e = env.alloc_rollout(K, keys=("obs", "reward", "terminated", "truncated"))
+                env.step_multi(cc_all[t * K:(t + 1) * K], mn_all[t * K:(t + 1) * K], rollout=roll_e if a.envg else None)
                 e1.record()
                 torch.cuda.synchronize()
                 if t >= 10:
@@ -108,6 +116,28 @@ def main():
                 real += (st[ok, 29] - st[ok, 30]).mean()  # 100 MHz ticks from probe 0 to probe 3
                 n += 1
                 continue
+            if a.envg:
+                seq = [24, 25, 26, 27, 0, 16, 1, 2, 14, 15]  # (slots the frame kernel running beside it does not write)
+                ok = (st[:, seq] > 0).all(axis=1) & (np.diff(st[:, seq], axis=1) >= 0).all(axis=1)
+                ab.append(np.diff(st[ok][:, seq], axis=1).astype(np.float64))
+                n += 1
+                continue
+            if a.frame:  # probes 3 (kernel entry) .. 13 and the second-level ones inside them
+                ok = (st[:, 3:14] > 0).all(axis=1) & (np.diff(st[:, 3:14], axis=1) >= 0).all(axis=1)
+                for name, i0, i1 in SUB[5:]:
+                    ok &= (st[:, i1] >= st[:, i0]) & (st[:, i0] >= st[:, 3]) & (st[:, i1] <= st[:, 13])
+                d = np.diff(st[ok, 3:14], axis=1)
+                acc[3:] += d.mean(axis=0)
+                life += (st[ok, 13] - st[ok, 3]).mean()
+                lives.append(st[ok, 13] - st[ok, 3])
+                sims.append(st[ok, 7] - st[ok, 3])
+                real += (st[ok, 31] - st[ok, 30]).mean()
+                for name, i0, i1 in SUB[5:]:
+                    sub[name] = sub.get(name, 0.0) + (st[ok, i1] - st[ok, i0]).mean()
+                for name, _, _ in SUB[:5]:
+                    sub[name] = 0.0
+                n += 1
+                continue
             # envs that ran every phase in THIS step (not re-spawned without info, at least one segment drawn ...): with
             # several steps per launch a probe a step skipped still holds an older step's stamp, hence the order test
             ok = (st[:, :24] > 0).all(axis=1) & (np.diff(st[:, :14], axis=1) >= 0).all(axis=1)
@@ -123,6 +153,18 @@ def main():
             for name, i0, i1 in SUB:
                 sub[name] = sub.get(name, 0.0) + (st[ok, i1] - st[ok, i0]).mean()
             n += 1
+        if a.envg:
+            dd = np.concatenate(ab)
+            print(f"--- {a.workload} tc_envg_kernel, {N} envs, {a.multi} steps per call, TC_CHUNK={os.environ.get('TC_CHUNK', 'default')}: "
+                  f"one step takes {dd.sum(axis=1).mean():.0f} clocks (mean over {len(dd)} stamped env-steps)")
+            for nm, v in zip(["top of step -> action loaded", "kinematics", "lanepath tracking (find_local_path)",
+                              "info: cte / heading, grid cell", "phase B layer 0: edge scan", "phase B layer 0: group argmin",
+                              "phase B layer 0: tail (bounds, distance)", "phase B layers 1..C-1", "terms, rollout rows, pose row"],
+                             dd.mean(axis=0)):
+                print(f"  {nm:52s} {v:9.0f}")
+            env.close()
+            nat.check(L.tc_debug_tstamp_alloc(0), "tstamp_free")
+            continue
         acc /= n
         life /= n
         real /= n

@@ -5,7 +5,7 @@ usage: python tools/summarize_pmc.py <tag> <name> [--round r02] [--rows-per-disp
 import argparse, collections, csv, glob, json, os
 ap = argparse.ArgumentParser()
 ap.add_argument("tag"); ap.add_argument("name")
-ap.add_argument("--round", default="r02"); ap.add_argument("--rows-per-dispatch", type=float, default=16, help="steps one dispatch of the workload's kernels covers (launch_info steps_per_dispatch)"); ap.add_argument("--build", default="?")
+ap.add_argument("--round", default="r02"); ap.add_argument("--rows-per-dispatch", type=float, default=16, help="steps one dispatch of the workload's kernels covers (launch_info steps_per_dispatch)"); ap.add_argument("--build", default="?"); ap.add_argument("--envs", type=int, default=0, help="envs per GPU: the steps a tc_frame_kernel dispatch covers are then taken from its grid (64 x envs x steps work-items)")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles", a.round)
@@ -33,6 +33,8 @@ for k, gs in by_kernel.items():
     res[k]["_dispatches_averaged"] = max(len(v) for v in gs[g].values())
 res["_note"] = "per-launch means over the profiled launches of the most frequent grid size; FETCH_SIZE/WRITE_SIZE in KB as rocprofv3 reports them"
 res["_rows_per_dispatch"] = a.rows_per_dispatch
+if a.envs and "tc_frame_kernel" in res:
+    res["_rows_per_dispatch"] = res["tc_frame_kernel"]["_grid_size"] / (64.0 * a.envs)
 res["_build"] = a.build
 json.dump(res, open(os.path.join(out, f"{a.name}_pmc.json"), "w"), indent=1, sort_keys=True)
 rows = []
