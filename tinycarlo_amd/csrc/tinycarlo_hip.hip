@@ -2476,6 +2476,7 @@ struct tc_env {
   // env (measured on cfg3: 70.9 us per step against a mean of 41 us per wavefront-step).  Frames are independent of
   // each other, and K x N workgroups are many more than the chip holds at once, so the dispatcher balances them.
   int multi_split;
+  int chunk_div;    // a call shorter than chunk_div chunks is cut into chunk_div pieces (TC_CHUNK_DIV, default 4)
   int chunk;        // K-step calls with a rollout: steps per simulate launch when the call is pipelined (TC_CHUNK, 0 = off)
   hipStream_t frame_stream;
   hipEvent_t sim_ev, frames_ev;
@@ -2757,6 +2758,8 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   if (const char* ml = getenv("TC_ENVG_MAP_LDS")) e->envg_map_lds = atoi(ml) != 0;
   e->chunk = 16;
   if (const char* ch = getenv("TC_CHUNK")) e->chunk = atoi(ch) > 0 ? atoi(ch) : 0;
+  e->chunk_div = 4;
+  if (const char* cd = getenv("TC_CHUNK_DIV")) e->chunk_div = atoi(cd) > 0 ? atoi(cd) : 4;
   e->frame_stream = nullptr;
   e->sim_ev = e->frames_ev = nullptr;
   memset(e->prof_piped, 0, sizeof(e->prof_piped));
@@ -3331,7 +3334,8 @@ static int noise_advance(tc_env* e, int mode, bool rendered, int nsteps, void* s
 static int chunk_steps(const tc_env* e, int nsteps, bool frames, bool all) {
   const bool can_pipe = frames && e->env_grouped && e->chunk > 0 && all && nsteps > 1;
   if (!can_pipe) return nsteps;
-  const int q = (nsteps + 3) / 4;
+  const int dv = e->chunk_div > 0 ? e->chunk_div : 4;
+  const int q = (nsteps + dv - 1) / dv;
   return e->chunk < q ? e->chunk : (q < 2 ? 2 : q);
 }
 
@@ -3423,7 +3427,9 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     // per step with the ramp, 50.3 / 43.7 / 39.5 with equal chunks; 50.9 with no pipelining at all).
     const bool can_pipe = frames && e->env_grouped && e->chunk > 0 && all && nsteps > 1;
     static const int ramp = getenv("TC_RAMP") ? atoi(getenv("TC_RAMP")) : 0;
-    int chunk = (can_pipe && ramp) ? 1 : chunk_steps(e, nsteps, frames, all);
+    int chunk = (can_pipe && ramp == 1) ? 1 : chunk_steps(e, nsteps, frames, all);
+    const int chunk_full = chunk;
+    if (can_pipe && ramp == 2) chunk = chunk / 4 < 2 ? 2 : chunk / 4;  // a short first chunk: less un-overlapped simulate time
     const bool piped = can_pipe;
     hipStream_t fs = piped ? e->frame_stream : main;
     const size_t esz = cdtype == TC_F32 ? 4 : 8;
@@ -3431,7 +3437,8 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     (void)thick;
     (void)cls;
     bool first_frames = true;
-    for (int c0 = 0, cn = 0; c0 < nsteps; c0 += cn, chunk = !(can_pipe && ramp) ? chunk : (chunk * 2 <= e->chunk ? chunk * 2 : e->chunk)) {
+    for (int c0 = 0, cn = 0; c0 < nsteps;
+         c0 += cn, chunk = !(can_pipe && ramp) ? chunk : ramp == 2 ? chunk_full : (chunk * 2 <= e->chunk ? chunk * 2 : e->chunk)) {
       cn = nsteps - c0 < chunk ? nsteps - c0 : chunk;
       const size_t r0 = (size_t)c0 * N;  // first [step][env] row of this chunk
       StepArgs sa;

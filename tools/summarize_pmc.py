@@ -31,6 +31,8 @@ for k, gs in by_kernel.items():
     res[k] = {c: sum(v) / len(v) for c, v in gs[g].items()}
     res[k]["_grid_size"] = g
     res[k]["_dispatches_averaged"] = max(len(v) for v in gs[g].values())
+    if res[k]["_dispatches_averaged"] < 3:  # a reset / one-off launch of another shape, not the workload's kernel
+        del res[k]
 res["_note"] = "per-launch means over the profiled launches of the most frequent grid size; FETCH_SIZE/WRITE_SIZE in KB as rocprofv3 reports them"
 res["_rows_per_dispatch"] = a.rows_per_dispatch
 if a.envs and "tc_frame_kernel" in res:
