@@ -742,14 +742,20 @@ __device__ inline long long d_sdiv(long long n, long long d) {
   long long an = n < 0 ? -n : n, ad = d < 0 ? -d : d;
   if (an < (1LL << 50) && ad < (1LL << 50)) {
     // quotient estimate from a hardware reciprocal (relative error ~2^-50: off by at most one for an < 2^50),
-    // made exact by the remainder test -- the result is the true integer quotient, no rounding mode involved
-    long long q = (long long)((double)an * __builtin_amdgcn_rcp((double)ad));
-    long long r = an - q * ad;
-    if (r < 0) {
-      q--;
-      r += ad;
+    // made exact by the remainder test -- the result is the true integer quotient, no rounding mode involved.
+    // The remainder an - q * ad is taken with ONE fused multiply-add in double precision instead of a 64 x 64-bit
+    // integer multiply (four quarter-rate v_mul / v_mad_u64_u32): an, ad and q are integers below 2^53, exact as doubles;
+    // the fma forms q * ad exactly and rounds an - q * ad once, and that value is an integer of magnitude <= 2 ad < 2^51,
+    // so the rounding is exact too.
+    const double dn = (double)an, dd = (double)ad;
+    double qd = __builtin_trunc(dn * __builtin_amdgcn_rcp(dd));
+    double rd = __builtin_fma(-qd, dd, dn);
+    if (rd < 0) {
+      qd -= 1.0;
+      rd += dd;
     }
-    if (r >= ad) q++;
+    if (rd >= dd) qd += 1.0;
+    const long long q = (long long)qd;
     return ((n < 0) != (d < 0)) ? -q : q;
   }
   return n / d;
@@ -941,7 +947,15 @@ __device__ inline void r_fill_row(const Ras& r, int row, int np, int wmask, cons
   for (int s = 0; s < np; s++) {
     const int ys = py[s];
     if (ys <= row) {
-      long long x = px[s] + (long long)(row - ys) * pdx[s];
+      // (row - ys) < 2^15; a slope that fits 32 bits (every edge that is not within a hair of horizontal) takes one
+      // 32 x 32 -> 64-bit multiply instead of the three quarter-rate instructions of the 32 x 64-bit product
+      // (the choice is made for the whole wavefront: a per-lane select would evaluate both products)
+      const long long sl = pdx[s];
+      long long x = px[s];
+      if (__ballot(sl != (long long)(int)sl) == 0)
+        x += (long long)(row - ys) * (long long)(int)sl;
+      else
+        x += (long long)(row - ys) * sl;
       if ((wmask >> s) & 1)
         xb = x;
       else

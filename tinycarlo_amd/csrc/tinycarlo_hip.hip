@@ -113,6 +113,7 @@ __device__ long long* tc_tstamp = nullptr;  // [N][32]
 #define DBG_SKIP_QUAD 0x80000u
 #define DBG_SKIP_CLIP 0x100000u
 #define DBG_SKIP_DRAWLIST 0x200000u
+#define RF_ZERO_FIRST 0x1000000u  // raster stage, rgb: zero the whole frame before the first band (TC_RGB_ZERO_FIRST=1)
 // the kernels test them only in the ablation build (make dev-ablate): in the shipped library every test folds to false,
 // so the switches cost no scalar registers there (they were ~25 live conditions at the head of the raster stage)
 #ifdef TC_ABLATE
@@ -120,6 +121,12 @@ __device__ long long* tc_tstamp = nullptr;  // [N][32]
 #else
 #define DBG_ON(word, f) false
 #endif
+
+// Every workgroup of the stage kernels is ONE wavefront, and the LDS executes a wavefront's operations in program order:
+// between phases that hand data from lane to lane through LDS nothing has to be waited for except the LDS queue itself
+// (and the compiler kept from moving memory operations across).  __syncthreads() would also drain the vector-memory
+// counter -- the frame's stores still in flight at the end of a band, the next batch's draw-list loads.
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // A reference into the kernel-argument segment, passed through an empty asm: the compiler can no longer tell that two
 // reads go to the same block, so values loaded behind this point are not merged with (and kept alive from) earlier
@@ -440,7 +447,7 @@ __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>
       flg[i] = (unsigned char)((p[2] < 0 ? 1 : 0) | (p[2] > -max_range ? 2 : 0));
     }
   }
-  __syncthreads();
+  lds_sync();
   TSTAMP(4);
   int ff[K];  // flags of the two ends of edge slot k: flg[ed.x] | flg[ed.y] << 8 (0 for an empty slot)
 #pragma unroll
@@ -472,7 +479,7 @@ __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>
         }
         n += __popcll(mk);
       }
-      __syncthreads();
+      lds_sync();
       // the usual case: every straddling edge has a target node of its own -> one move each, order irrelevant
       bool dup = n > TC_NT;
       int mine = 0;
@@ -491,7 +498,7 @@ __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>
       } else {
         cam_chain_replay(Px, Py, Pz, flg, bit, tz, list, n, max_range, pass < 2, tid);
       }
-      __syncthreads();
+      lds_sync();
 #pragma unroll
       for (int k = 0; k < K; k++) ff[k] = k * TC_NT + tid < ne ? (int)flg[mc.ed[k].x] | ((int)flg[mc.ed[k].y] << 8) : 0;
     }
@@ -512,7 +519,7 @@ __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>
       flg[mc.ed[k].y] = (unsigned char)(fb | 16);
     }
   }
-  __syncthreads();
+  lds_sync();
   int ncand = 0;
 #pragma unroll
   for (int k = 0; k < K; k++) {
@@ -522,7 +529,7 @@ __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>
     if (c) list[ncand + wave_rank(mk)] = i;
     ncand += __popcll(mk);
   }
-  __syncthreads();
+  lds_sync();
   for (int k = tid; k < ncand; k += TC_NT) {  // camera.py:133-142, 90
     const int i = list[k];
     double u, v;
@@ -531,7 +538,7 @@ __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>
     ((int2*)Px)[i] = q;  // renderer.py:43,50 np.int32(...)
     if (vis) flg[i] |= 4;
   }
-  __syncthreads();
+  lds_sync();
   TSTAMP(6);
   // camera.py:95: the edges with a visible end, compacted first (edge id, end nodes) so that the code that emits a
   // segment runs once over a dense list instead of once per register slot with a few lanes active in each
@@ -548,7 +555,7 @@ __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>
     }
     ndraw += __popcll(mk);
   }
-  __syncthreads();
+  lds_sync();
   for (int j = tid; j < ndraw; j += TC_NT) {  // both ends were marked above and hold pixel coordinates
     const int e = list[2 * j], xy = list[2 * j + 1];
     const int2 pa = ((int2*)Px)[xy & 0xffff], pb = ((int2*)Px)[(unsigned)xy >> 16];
@@ -563,7 +570,7 @@ __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>
     o[4] = pb.y;
   }
   nseg += ndraw;
-  __syncthreads();  // the next group reuses the node buffer
+  lds_sync();  // the next group reuses the node buffer
 }
 
 template <int K>
@@ -1341,13 +1348,24 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
   int* fpv = fpy + 4 * RB;                // [RB][4] fill pieces: polygon vertices idx0 | idx << 2
   long long* fpx = (long long*)(fpv + 4 * RB);  // [RB][4] x at the start row (16.16)
   long long* fpd = fpx + 4 * RB;          // [RB][4] dx per row
+  const bool zero_first = (a.flags & RF_ZERO_FIRST) != 0;
+  if (FMT != TC_FMT_CLASSES && (W & 15) == 0 && zero_first) {
+    // rgb: lane lines cover ~1 % of a frame.  The WHOLE frame is written as zeros with coalesced 16-byte stores up
+    // front -- they drain while the bands are rasterised -- and each band then only revisits the pixels that have a bit
+    // set in some plane.  (Zeroing band by band put a wait for the band's zeros in front of its pixel stores: 12-19
+    // store round trips per 480x640 frame with nothing to overlap them.)
+    const int n16 = H * W * 3 / 16;
+    uint4* dst = (uint4*)out;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int q = tid; q < n16; q += TC_NT) dst[q] = z;
+  }
   for (int band = 0; band < cam.n_bands; band++) {
     const int y0 = band * cam.band_rows;
     const int y1 = (y0 + cam.band_rows < H) ? y0 + cam.band_rows : H;
     const int rows = y1 - y0;
     const int nwords = C * cam.band_rows * wpr;
     for (int i = tid; i < nwords; i += TC_NT) bits[i] = 0;
-    __syncthreads();
+    lds_sync();
     TSTAMP(9);
     Ras r;
     r.W = W;
@@ -1412,7 +1430,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
           fd[2 * tid] = dpx;
           fd[2 * tid + 1] = dpy;
         }
-        __syncthreads();
+        lds_sync();
         TSTAMP(10);
         for (int t = tid; t < RB * 4; t += TC_NT) {  // outline edges: clip + DDA parameters
           int nchunk = 0;
@@ -1453,7 +1471,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
           }
           lc[t] = nchunk;
         }
-        __syncthreads();
+        lds_sync();
         int tot_l, tot_f;
         {  // exclusive prefix sums (RB*4 = 2 entries per lane; RB entries on the low lanes)
           int v0 = lc[2 * tid], v1 = lc[2 * tid + 1];
@@ -1466,7 +1484,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
           lc[2 * tid + 1] = inc - v1;
           if (tid < RB) fc[tid] = finc - f;
         }
-        __syncthreads();
+        lds_sync();
         TSTAMP(11);
         for (int c = tid; c < tot_l && !DBG_ON(a.flags, DBG_SKIP_R2); c += TC_NT) {  // outline pixels, LCH steps per chunk
           int lo = 0, hi = RB * 4;
@@ -1503,10 +1521,10 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
           else
             r_circle_fill(r, cx, cy, cam.cap_r);
         }
-        __syncthreads();
+        lds_sync();
       }
     }
-    __syncthreads();
+    lds_sync();
     if (FMT == TC_FMT_CLASSES && a.noise_blobs > 0) {
       // NoiseObservationWrapper (wrapper/observation.py:15-27) on the bit-planes, before they are expanded: the frame
       // never makes the extra round trip through HBM a pass of its own costs (71 us per step on cfg3 in round 1).
@@ -1526,7 +1544,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
         bp[2 * k] = bl.x | (bl.y << 16);
         bp[2 * k + 1] = bl.r | (bl.mode << 12) | (bl.src << 16);
       }
-      __syncthreads();
+      lds_sync();
       if (staged) {  // half width of every (blob, row of this band): one table byte each, fetched with the loads in flight
         for (int row = tid; row < rows; row += TC_NT) {
 #pragma unroll 5
@@ -1537,7 +1555,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
             bh[k * rows + row] = t <= rr ? a.noise_hw[rr * mr + t] : (unsigned char)0;
           }
         }
-        __syncthreads();
+        lds_sync();
       }
       const int items = rows * wpr;
       for (int it = tid; it < items; it += TC_NT) {
@@ -1571,7 +1589,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
           bits[(c * cam.band_rows + row) * wpr + w] = cur;
         }
       }
-      __syncthreads();
+      lds_sync();
       used_layers = C >= 32 ? 0xffffffffu : ((1u << C) - 1u);  // a copy may have filled a plane that had no segment
     }
     TSTAMP(12);
@@ -1625,14 +1643,16 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
     } else {
       // rgb: painter's order (renderer.py:41-43): the highest layer covering a pixel wins
       if ((W & 15) == 0) {
-        // Lane lines cover ~1 % of an rgb frame.  Write the band as zeros with coalesced 16-byte stores,
-        // then revisit only the pixels that have a bit set in some plane (byte stores into lines this
-        // wavefront has just written).
-        const int n16 = rows * W * 3 / 16;
-        uint4* dst = (uint4*)(out + (size_t)y0 * W * 3);
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        for (int q = tid; q < n16; q += TC_NT) dst[q] = z;
-        __syncthreads();  // vmcnt(0): the zeros are in the memory system before the sparse stores are issued
+        // zeros first (the whole frame before the first band, or this band's rows here), then only the pixels that have
+        // a bit set in some plane; the zeros must be in the memory system before the pixel stores go out (byte stores
+        // into lines this wavefront has written)
+        if (!zero_first) {
+          const int n16 = rows * W * 3 / 16;
+          uint4* dst = (uint4*)(out + (size_t)y0 * W * 3);
+          const uint4 z = make_uint4(0, 0, 0, 0);
+          for (int q = tid; q < n16; q += TC_NT) dst[q] = z;
+        }
+        if (band == 0 || !zero_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int nw = rows * wpr;
         for (int q = tid; q < nw; q += TC_NT) {
           unsigned int any = 0;
@@ -1693,7 +1713,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
         }
       }
     }
-    __syncthreads();
+    lds_sync();
   }
   TSTAMP(13);
   TSTAMP_REAL(31);
@@ -2887,6 +2907,17 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   off += 64;
   L.total = off;
   // raster kernel: tables + bit-planes of one band
+  // A frame taller than one band: the workgroup's LDS is the larger of the two stages' needs, and how many workgroups a
+  // CU holds decides the rate of the big frames (cfg5: 6 per CU at 23.2 KB, 9 at 17.4 KB: 3.10 -> 3.82 M env-steps/s).
+  // So the band shrinks until the raster stage needs no more than the camera stage does anyway -- not further: more
+  // bands only repeat the per-band set-up (measured: 8 KB and 6 KB bands are slower again).
+  if (dc.n_bands > 1 && !getenv("TC_BAND_BYTES")) {
+    const int fit = (L.total - R_OFF_BITS) / row_bytes;
+    if (fit >= 8 && fit < dc.band_rows) {
+      dc.band_rows = band_rows = fit;
+      dc.n_bands = (dc.H + band_rows - 1) / band_rows;
+    }
+  }
   e->r_off_tab = R_OFF_TAB;
   e->r_off_bits = R_OFF_BITS;
   e->r_lds = e->r_off_bits + align_up(m.C * band_rows * dc.wpr * 4, 16);
@@ -3285,7 +3316,8 @@ static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_c
   r.mask = mask;
   r.off_tab = e->r_off_tab;
   r.off_bits = e->r_off_bits;
-  r.flags = flags;
+  static const bool zero_first = getenv("TC_RGB_ZERO_FIRST") && atoi(getenv("TC_RGB_ZERO_FIRST")) != 0;
+  r.flags = flags | (zero_first ? RF_ZERO_FIRST : 0u);
   r.seg_row0 = 0;
   r.obs_row_stride = 0;
   if (with_noise && e->noise_blobs > 0 && c.format == TC_FMT_CLASSES) {
@@ -3430,6 +3462,12 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     int chunk = (can_pipe && ramp == 1) ? 1 : chunk_steps(e, nsteps, frames, all);
     const int chunk_full = chunk;
     if (can_pipe && ramp == 2) chunk = chunk / 4 < 2 ? 2 : chunk / 4;  // a short first chunk: less un-overlapped simulate time
+    int chunk_rest = chunk_full;
+    if (can_pipe && ramp == 3 && nsteps > 4) {  // half a chunk first, the rest in equal chunks
+      chunk = (chunk_full + 1) / 2;
+      const int left = nsteps - chunk, nrest = (left + chunk_full - 1) / chunk_full;
+      chunk_rest = (left + nrest - 1) / nrest;
+    }
     const bool piped = can_pipe;
     hipStream_t fs = piped ? e->frame_stream : main;
     const size_t esz = cdtype == TC_F32 ? 4 : 8;
@@ -3438,7 +3476,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     (void)cls;
     bool first_frames = true;
     for (int c0 = 0, cn = 0; c0 < nsteps;
-         c0 += cn, chunk = !(can_pipe && ramp) ? chunk : ramp == 2 ? chunk_full : (chunk * 2 <= e->chunk ? chunk * 2 : e->chunk)) {
+         c0 += cn, chunk = !(can_pipe && ramp) ? chunk : ramp == 2 ? chunk_full : ramp == 3 ? chunk_rest : (chunk * 2 <= e->chunk ? chunk * 2 : e->chunk)) {
       cn = nsteps - c0 < chunk ? nsteps - c0 : chunk;
       const size_t r0 = (size_t)c0 * N;  // first [step][env] row of this chunk
       StepArgs sa;

@@ -6,7 +6,7 @@ FL=${@:-0 0x200 0x100 0x300 0x1000 0x2000 0x4000 0x10000 0x20000 0x40000 0x80000
 cd /tmp && export TMPDIR=/tmp
 for f in $FL; do
   rm -rf /tmp/pa_$f
-  TC_DEBUG_FLAGS=$f TC_CHUNK=0 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/pa_$f -- python3 $R/bench.py --workload $WL --steps 32 --warmup 16 --steps-per-launch 16 --preroll-ms 0 --no-cpu-baseline > /tmp/pa_$f.log 2>&1 || { echo "flags $f failed"; tail -3 /tmp/pa_$f.log; continue; }
+  TC_DEBUG_FLAGS=$f TC_CHUNK=0 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/pa_$f -- python3 $R/bench.py --workload $WL --steps 32 --warmup 2048 --steps-per-launch 16 --preroll-ms 0 --no-cpu-baseline > /tmp/pa_$f.log 2>&1 || { echo "flags $f failed"; tail -3 /tmp/pa_$f.log; continue; }
   python3 - "$f" <<'PY'
 import csv, glob, sys, collections
 f = sys.argv[1]
