@@ -2023,7 +2023,12 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) vo
 // The price is latency (a group of 8 lanes walks 33 edges per layer pass one after the other), which nobody waits for:
 // the kernel leaves most of the chip's issue slots free for the frame kernel of the previous call.
 #define TC_EL 8
+#ifndef TC_ENVG_NT
 #define TC_ENVG_NT 256  // threads per workgroup: 4 wavefronts = 32 envs share one LDS copy of the edge records
+#endif
+#ifndef TC_ENVG_PRIO
+#define TC_ENVG_PRIO 3
+#endif
 struct GroupLds {  // per env of the wavefront: what the reward / termination terms read and count
   double dist[TC_MAX_LAYERS];
   int cnt[TC_MAX_TERMS];
@@ -2041,7 +2046,7 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
   // Highest issue priority: when this kernel shares the chip with the frame kernel of the previous chunk it is the
   // critical path (a serial chain per step, few instructions), and the frame wavefronts would otherwise crowd it out
   // of the vector issue slots by sheer number (measured: 36 us per step beside them, 21 us alone).
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(TC_ENVG_PRIO);
   const StepArgs& s0 = step_args();
   const int lane = threadIdx.x, sub = lane & (TC_EL - 1), grp = lane / TC_EL;
   const int N = s0.a.N;
@@ -3505,7 +3510,12 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       sa.maneuver = man + r0;
       sa.spawn_nodes = spawn;
       sa.mask = mask;
-      if (frames && e->env_grouped) {
+      // The first chunk's simulate launch overlaps with nothing, so it should be SHORT rather than cheap: it goes through
+      // the one-wavefront-per-env kernel (4096 wavefronts, bound by throughput: ~15 us per step) instead of the grouped
+      // one (512 wavefronts, a latency chain: 13-23 us per step).  20-step call 48.4 -> 47.2 us per step, 128-step calls
+      // 38.2 -> 37.6.  Both kernels read and leave the env's state in the caller's buffers, bit for bit the same.
+      static const bool first_per_env = getenv("TC_FIRST_CHUNK_PER_ENV") ? atoi(getenv("TC_FIRST_CHUNK_PER_ENV")) != 0 : true;
+      if (frames && e->env_grouped && !(first_per_env && c0 == 0 && piped && nsteps > chunk)) {  // (a one-chunk call: grouped)
         const size_t map_bytes = (size_t)e->k.m.total_edges * 48;
         sa.ma.map_lds = (e->envg_map_lds && map_bytes <= 40 * 1024) ? 1 : 0;
         hipLaunchKernelGGL(tc_envg_kernel, dim3((N + TC_ENVG_NT / TC_EL - 1) / (TC_ENVG_NT / TC_EL)), dim3(TC_ENVG_NT),
