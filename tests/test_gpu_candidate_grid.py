@@ -133,3 +133,29 @@ def test_displaced_positions_grouped_kernel(mp, res):
     for k in range(5):
         assert int((have & (kind == k)).sum()) >= 10, (mp, k)
     env.close()
+
+
+def test_grid_switched_off_is_the_same(monkeypatch):
+    """TC_CAND_GRID=0: no grid is built and every env takes the identity list (the whole layer) through the same code --
+    the outputs of a golden single-step batch and of a short K-step call must not change."""
+    d = golden("single_simple_layout.npz")
+    pre = _states_from(d, "pre_")
+    cc = np.stack([d["v"], d["s"]], axis=1)
+    outs = []
+    for grid in ("1", "0"):
+        monkeypatch.setenv("TC_CAND_GRID", grid)
+        env = make_env("simple_layout", "r64", "classes", len(pre))
+        env.wrapped = True
+        push_state(env, pre)
+        env.step({"car_control": cc, "maneuver": d["maneuver"]})
+        K = 4
+        roll = env.alloc_rollout(K, keys=("obs", "reward", "cte"))
+        env.step_multi(torch.from_numpy(np.repeat(cc[None], K, axis=0)).cuda(),
+                       torch.from_numpy(np.repeat(d["maneuver"][None].astype(np.int32), K, axis=0)).cuda(), rollout=roll)
+        torch.cuda.synchronize()
+        outs.append((env.out["nearest_edge"].cpu().numpy().copy(), env.out["laneline_distances"].cpu().numpy().copy(),
+                     roll["cte"].cpu().numpy().copy(), roll["obs"].cpu().numpy().copy()))
+        env.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a.view(np.uint8) if a.dtype == np.float64 else a, b.view(np.uint8) if b.dtype == np.float64 else b)
+    assert (outs[0][0] >= 0).any()
