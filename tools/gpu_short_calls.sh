@@ -1,11 +1,8 @@
 #!/bin/bash
-# 20-step calls (the driver's command line): how the call is cut into pipelined chunks
+# short K-step calls (the driver's 20-step command): one or two frame streams
 cd "$(dirname "$0")/.."
-for dv in 4 2 3 1 5 7 10; do
-for K in 20; do
-TC_CHUNK_DIV=$dv timeout -k 10 300 python bench.py --steps $K --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('div=$dv K=$K', round(d['ms_per_step']*1e3,2), 'us/step; dispatches', r['dispatches_per_call'], {k: round(v,1) for k,v in r['kernels_us'].items()})"
+timeout -k 10 400 python -m pytest tests/test_gpu_step_multi.py -x -q -k "simple_layout-r64-classes or stress or against_oracle or wrap or noise" 2>&1 | tail -2
+for fs in 2 1; do
+for K in 8 20 40 64; do
+TC_FRAME_STREAMS=$fs timeout -k 10 300 python bench.py --steps $K --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('frame streams=$fs K=$K', round(d['ms_per_step']*1e3,2), 'us/step', round(d['value']/1e6,1), 'M; dispatches', r['dispatches_per_call'], 'of', r['steps_per_dispatch'], 'steps')"
 done; done
-TC_CHUNK=0 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('no pipelining K=20', round(d['ms_per_step']*1e3,2), 'us/step')"
-for dv in 4 2; do
-TC_CHUNK_DIV=$dv timeout -k 10 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('div=$dv K=40', round(d['ms_per_step']*1e3,2), 'us/step')"
-done
