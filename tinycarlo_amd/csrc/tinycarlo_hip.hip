@@ -661,12 +661,17 @@ __device__ inline int2 cam_project(const double* K, double X, double Y, double Z
   return make_int2(d_np_int32(u), d_np_int32(v));
 }
 
-__device__ inline int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int off = 1; off < TC_NT; off <<= 1) {
-    int o = __shfl_up(v, off);
-    if (lane >= off) v += o;
-  }
+// Inclusive prefix sum over the 64 lanes with DPP moves (register to register): Hillis-Steele inside each row of 16
+// (row_shr 1, 2, 4, 8, zeros shifted in), then lane 15 of a row added to the next row and lane 31 to the upper half
+// (row_bcast 15 / 31) -- instead of six ds_bpermute round trips through the LDS crossbar.  All 64 lanes must be active.
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+  (void)lane;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
   return v;
 }
 
@@ -1476,10 +1481,10 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
         {  // exclusive prefix sums (RB*4 = 2 entries per lane; RB entries on the low lanes)
           int v0 = lc[2 * tid], v1 = lc[2 * tid + 1];
           int inc = wave_incl_scan(v0 + v1, tid);
-          tot_l = __shfl(inc, TC_NT - 1);
+          tot_l = __builtin_amdgcn_readlane(inc, TC_NT - 1);
           int f = tid < RB ? fc[tid] : 0;
           int finc = wave_incl_scan(f, tid);
-          tot_f = __shfl(finc, TC_NT - 1);
+          tot_f = __builtin_amdgcn_readlane(finc, TC_NT - 1);
           lc[2 * tid] = inc - v0 - v1;  // each lane rewrites only the entries it read
           lc[2 * tid + 1] = inc - v1;
           if (tid < RB) fc[tid] = finc - f;
