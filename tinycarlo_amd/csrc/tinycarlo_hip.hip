@@ -204,6 +204,9 @@ struct KArgs {
   int spawn_n;
   unsigned long long spawn_seed;
   unsigned int dbg;  // DBG_* ablation switches for the camera stage of tc_frame_kernel (0 in every other launch)
+  // tc_frame_kernel: the first seg_lds_cap entries of the frame's draw list stay in LDS (byte offset seg_lds_off of the
+  // workgroup's block, behind both stages' buffers) instead of going through global memory; 0 in every other launch
+  int seg_lds_off, seg_lds_cap;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -412,6 +415,9 @@ __device__ inline void cam_chain_replay(double* Px, double* Py, double* Pz, unsi
 
 __device__ inline int2 cam_project(const double* K, double X, double Y, double Z, double& u, double& v);
 
+typedef __attribute__((address_space(3))) int* LdsIntPtr;  // (explicitly LDS: a select between it and a global pointer
+                                                            // cannot be folded into one flat access)
+
 // rank of this lane among the set bits of a wave ballot
 __device__ __forceinline__ int wave_rank(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -430,7 +436,8 @@ template <int K>
 __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>& mc, const double* pose, const double* Kc,
                                                const int l0, const int l1, const int ge0, const int nn, const int ne,
                                                double* Px, double* Py, double* Pz, unsigned char* flg, int* list,
-                                               int* segg, int& nseg, unsigned int& my_layers, const int env, const int tid) {
+                                               int* segg, LdsIntPtr seg_lds, int& nseg, unsigned int& my_layers, const int env,
+                                               const int tid) {
   const DevMap& m = a.m;
   const DevCam& cam = a.cam;
   const double max_range = cam.max_range;
@@ -562,12 +569,22 @@ __device__ __forceinline__ void cam_group_regs(const KArgs& a, const MapCache<K>
     int layer = l0;
     for (int c = l0 + 1; c < l1; c++) layer += (ge0 + e) >= m.edge_off[c];
     my_layers |= 1u << layer;
-    int* o = segg + 5 * (nseg + j);  // < seg_cap == total edge count
-    o[0] = layer;
-    o[1] = pa.x;
-    o[2] = pa.y;
-    o[3] = pb.x;
-    o[4] = pb.y;
+    const int js = nseg + j;  // < seg_cap == total edge count
+    if (js < a.seg_lds_cap) {  // the raster stage of this wavefront reads it back from LDS: no store -> load round trip
+      const LdsIntPtr o = seg_lds + 5 * js;
+      o[0] = layer;
+      o[1] = pa.x;
+      o[2] = pa.y;
+      o[3] = pb.x;
+      o[4] = pb.y;
+    } else {
+      int* o = segg + 5 * js;
+      o[0] = layer;
+      o[1] = pa.x;
+      o[2] = pa.y;
+      o[3] = pb.x;
+      o[4] = pb.y;
+    }
   }
   nseg += ndraw;
   lds_sync();  // the next group reuses the node buffer
@@ -1155,7 +1172,8 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
       cache_edges(mc, m, ge0, ge0 + ne, gn0, tid);
     }
     if (one) {
-      cam_group_regs<K>(a, mc, pose, Kc, l0, l1, ge0, nn, ne, Px, Py, Pz, flg, list, segg, nseg, my_layers, env, tid);
+      cam_group_regs<K>(a, mc, pose, Kc, l0, l1, ge0, nn, ne, Px, Py, Pz, flg, list, segg, (LdsIntPtr)(smem + a.seg_lds_off), nseg,
+                        my_layers, env, tid);
       continue;
     }
     // a group larger than the register window (no bundled map): window by window, lists and counters in LDS
@@ -1315,6 +1333,7 @@ struct RArgs {
   const unsigned char* noise_hw;
   unsigned long long noise_seed;
   const unsigned int* noise_step;
+  int seg_lds_off, seg_lds_cap;  // see KArgs
 };
 
 #ifndef TC_RASTER_WAVES
@@ -1328,6 +1347,25 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
   const RCam& cam = a.cam;
   unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
   const int* segg = a.seg_g + (seg_slot0 + env) * a.seg_cap * 5;
+  // draw-list entry k: from LDS when the camera stage of this wavefront left it there (tc_frame_kernel), else global
+  const LdsIntPtr seg_lds = (LdsIntPtr)(smem + a.seg_lds_off);
+  const int seg_lds_cap = a.seg_lds_cap;
+  struct SegV {
+    int v[5];
+    __device__ __forceinline__ int operator[](int i) const { return v[i]; }
+  };
+  auto seg_get = [&](int k) {
+    SegV r;
+    if (k < seg_lds_cap) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) r.v[i] = seg_lds[5 * k + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; i++) r.v[i] = segg[5 * k + i];
+    }
+    return r;
+  };
+  auto seg_layer = [&](int k) { return k < seg_lds_cap ? seg_lds[5 * k] : segg[5 * k]; };
   // draw-list length and the layers that have a segment in this frame (wave-uniform): handed over in registers by the
   // camera stage of the same wavefront, or read back when this is a launch of its own (nseg_in < 0)
   int nseg = nseg_in;
@@ -1382,7 +1420,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
     if (DBG_ON(a.flags, DBG_SKIP_RASTER)) {
     } else if (!THICK) {
       for (int k = tid; k < nseg; k += TC_NT) {
-        const int* sg = segg + 5 * k;
+        const SegV sg = seg_get(k);
         r.bits = bits + sg[0] * plane;
         r_line_bresenham(r, sg[1], sg[2], sg[3], sg[4]);  // ThickLine with thickness <= 1 is a plain Line()
       }
@@ -1399,7 +1437,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
         if (tid < RB) {  // per segment: ThickLine's dp, fill walker pieces, fill rows of this band
           int nrow = 0, lo = 0, np = 0, wm = 0, dpx = 0, dpy = 0, okq = 0;
           if (tid < nb) {
-            const int* sg = segg + 5 * (base + tid);
+            const SegV sg = seg_get(base + tid);
             long long qx0, qx1, qx2, qx3, qy0, qy1, qy2, qy3;
             TSTAMP(20);
             // Frames taller than one LDS band are rasterised band by band, and every band runs this set-up again.  A
@@ -1441,7 +1479,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
           int nchunk = 0;
           if (t < nb * 4 && ((fm[t >> 2] >> 16) & 1)) {
             const int j = t >> 2, e = t & 3;
-            const int* sg = segg + 5 * (base + j);
+            const SegV sg = seg_get(base + j);
             const long long p0x = (long long)sg[1] * TC_XY_ONE, p0y = (long long)sg[2] * TC_XY_ONE;
             const long long p1x = (long long)sg[3] * TC_XY_ONE, p1y = (long long)sg[4] * TC_XY_ONE;
             const long long dpx = fd[2 * j], dpy = fd[2 * j + 1];
@@ -1512,12 +1550,12 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
           }
           const int row = fl[lo] + (c - fc[lo]);
           const int mm = fm[lo];
-          r.bits = bits + segg[5 * (base + lo)] * plane;
+          r.bits = bits + seg_layer(base + lo) * plane;
           r_fill_row(r, row, mm & 0xff, (mm >> 8) & 0xff, fpy + 4 * lo, fpx + 4 * lo, fpd + 4 * lo);
         }
         for (int t = tid; t < nb * 2 && !DBG_ON(a.flags, DBG_SKIP_R4); t += TC_NT) {  // round caps (flags = 3: both ends)
           const int k = base + (t >> 1);
-          const int* sg = segg + 5 * k;
+          const SegV sg = seg_get(k);
           r.bits = bits + sg[0] * plane;
           const int cx = (t & 1) ? sg[3] : sg[1], cy = (t & 1) ? sg[4] : sg[2];
           if (cam.n_bands > 1 && ((long long)cy + cam.cap_r < y0 || (long long)cy - cam.cap_r >= y1)) continue;  // cap outside the band
@@ -2386,7 +2424,10 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame
   TSTAMP(3);
   TSTAMP_REAL(30);
   cam_body<K>(fa.a, smem, env, pose, mc, false, tid, row, nseg, used);
-  __syncthreads();  // draw list written by this wavefront is visible to it (vmcnt(0) + barrier)
+  if (nseg > fa.a.seg_lds_cap)
+    __syncthreads();  // draw-list entries that went through global memory are visible to this wavefront (vmcnt(0) + barrier)
+  else
+    lds_sync();
   const FrameArgs& fr = frame_args();
   raster_body<THICK, FMT>(fr.r, smem, env, fr.r.obs + (size_t)blockIdx.y * fr.r.obs_row_stride, tid, slot0, nseg, used, row);
 }
@@ -2510,6 +2551,7 @@ struct tc_env {
   int chunk;        // K-step calls with a rollout: steps per simulate launch when the call is pipelined (TC_CHUNK, 0 = off)
   hipStream_t frame_stream, frame_stream2;
   hipEvent_t sim_ev, frames_ev, frames_ev2;
+  int frame_lds, seg_lds_off, seg_lds_cap;  // tc_frame_kernel: LDS bytes per workgroup, draw-list region (see KArgs)
   int frame_streams;  // short K-step calls: frame launches of consecutive chunks alternate between two streams (TC_FRAME_STREAMS)
   int prof_piped[TC_PROF_RING];
   int envg_map_lds; // tc_envg_kernel keeps the edge records in LDS when they fit (TC_ENVG_MAP_LDS=0: always from global)
@@ -2710,6 +2752,7 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
               if (f[e - e0] <= thr) cidx.push_back(e);
             coff[((size_t)base + (size_t)iy * nx + ix) * C + l + 1] = (int)cidx.size();
           }
+          if (cidx.size() > (size_t)48 << 20) return -1;  // a map on which the lists do not thin out (192 MB of ids): no grid
         }
       return base;
     };
@@ -2718,14 +2761,17 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
       double cell = sqrt((x1 - x0) * (y1 - y0) / 65536.0);
       if (cell < 0.04) cell = 0.04;
       const int nx = (int)ceil((x1 - x0) / cell), ny = (int)ceil((y1 - y0) / cell);
-      if (nx >= 1 && ny >= 1 && (long long)nx * ny <= 200000) {
-        add_level(x0, y0, cell, nx, ny);
+      if (nx >= 1 && ny >= 1 && (long long)nx * ny <= 200000 && add_level(x0, y0, cell, nx, ny) >= 0) {
         d.grid_nx = nx;
         d.grid_ny = ny;
         d.grid_x0 = x0;
         d.grid_y0 = y0;
         d.grid_inv = 1.0 / cell;
       }
+    }
+    if (d.grid_nx == 0) {  // no grid (or abandoned): the kernels take the identity lists
+      coff.assign(1, 0);
+      cidx.clear();
     }
     if (cidx.empty()) cidx.push_back(0);
   }
@@ -2939,13 +2985,34 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   // the env's parked state (tc_step_multi) sits behind whichever stage needs more, so that neither aliases it
   L.off_live = align_up(L.total > e->r_lds ? L.total : e->r_lds, 16);
   L.total = L.off_live + TC_LIVE_BYTES;
+  {
+    // tc_frame_kernel keeps no env state in LDS, so the bytes behind both stages' buffers -- the LiveLds slot and whatever
+    // the workgroup can grow without costing the CU a workgroup (160 KB / workgroups per CU, in 1280-byte steps) --
+    // hold the head of the frame's draw list: the raster stage reads what the camera stage of the same wavefront just
+    // wrote without a round trip through global memory (cfg3: 44 of a frame's ~20-30 segments).
+    const int cu_lds = 160 * 1024;
+    const int w = cu_lds / L.total > 0 ? cu_lds / L.total : 1;
+    int grown = cu_lds / w / 1280 * 1280;
+    if (grown > L.total + 4096) grown = L.total + 4096;  // (200 segments are plenty)
+    if (grown < L.total) grown = L.total;
+    e->frame_lds = grown;
+    e->seg_lds_off = L.off_live;
+    e->seg_lds_cap = (grown - L.off_live) / 20;
+    if (const char* sl = getenv("TC_SEG_LDS")) {
+      if (atoi(sl) == 0) {
+        e->seg_lds_cap = 0;
+        e->frame_lds = L.total;
+      }
+    }
+  }
   if (L.total > 160 * 1024 || e->r_lds > 160 * 1024) {
     set_err("tc_env_create: map too large for one workgroup's LDS");
     delete e;
     return TC_E_LDS;
   }
   {
-    const int lds = L.total > e->r_lds ? L.total : e->r_lds;
+    int lds = L.total > e->r_lds ? L.total : e->r_lds;
+    if (e->frame_lds > lds) lds = e->frame_lds;
     if (lds > 48 * 1024) {
       for (int t = 0; t < 2; t++)
         for (int c = 0; c < 2; c++) {
@@ -3575,7 +3642,9 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
           fa.r = rr;
           fa.pose_rows = e->pose_rows;
           frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
-          hipLaunchKernelGGL(fk, dim3(N, ny), dim3(TC_NT), e->k.lds.total, fs, fa);
+          fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
+          fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->seg_lds_cap;
+          hipLaunchKernelGGL(fk, dim3(N, ny), dim3(TC_NT), e->frame_lds, fs, fa);
         } else {
 #ifdef TC_DEV_FAST
           auto rk = tc_raster_kernel<true, TC_FMT_CLASSES>;
