@@ -620,9 +620,10 @@ __device__ inline void r_hline(const Ras& r, int y, int xl, int xr) {
 
 // Filled circle (round cap) from its per-row half widths hw[|dy|], dy = -rad..rad: the pixel set of
 // Circle(center, rad, fill) is the union of centred spans, so per row only the widest one matters.
-__device__ inline void r_cap(const Ras& r, int cx, int cy, int rad, const unsigned char* hw) {
+__device__ inline void r_cap(const Ras& r, int cx, int cy, int rad, const unsigned char* hw, unsigned int hw4) {
   for (int dy = -rad; dy <= rad; dy++) {
-    const int h = hw[dy < 0 ? -dy : dy];
+    const int ady = dy < 0 ? -dy : dy;
+    const int h = rad <= 3 ? (int)((hw4 >> (8 * ady)) & 255u) : (int)hw[ady];
     long long y = (long long)cy + dy, xl = (long long)cx - h, xr = (long long)cx + h;
     const bool ok = y >= 0 && y < r.H && xr >= 0 && xl < r.W;
     r_hline(r, ok ? (int)y : -1, ok ? (int)(xl < 0 ? 0 : xl) : 1, ok ? (int)(xr > r.W - 1 ? r.W - 1 : xr) : 0);

@@ -1115,8 +1115,14 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
 #define TC_POSE_ROW 16  // doubles per (step, env) pose row: the 12 entries, padded to 128 bytes
 __device__ __forceinline__ void cam_pose12(const KArgs& a, int env, const FramePose& fp, double* pose) {
   double Ec[12];  // this env's camera (camera.py:23-24,48-50): shared, or its own after tc_env_set_camera_per_env
+  if (a.cam_E) {
 #pragma unroll
-  for (int i = 0; i < 12; i++) Ec[i] = a.cam_E ? a.cam_E[(size_t)env * 12 + i] : a.cam.E[i];
+    for (int i = 0; i < 12; i++) Ec[i] = a.cam_E[(size_t)env * 12 + i];
+  } else {
+    const __attribute__((address_space(4))) double* ee = (const __attribute__((address_space(4))) double*)(unsigned long long)a.cam.E;
+#pragma unroll
+    for (int i = 0; i < 12; i++) Ec[i] = ee[i];
+  }
   const double cth = fp.cth, sth = fp.sth;
   double R[16] = {cth, -sth, 0, 0, sth, cth, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   double Tm[16] = {1, 0, 0, -fp.x, 0, 1, 0, -fp.y, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -1145,8 +1151,14 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
   int* cnt = (int*)(smem + a.lds.off_cnt);
   const DevCam& cam = a.cam;
   double pose[12], Kc[9];
+  if (a.cam_K) {  // (a branch, not a select of pointers: the shared camera's K then comes in scalar loads)
 #pragma unroll
-  for (int i = 0; i < 9; i++) Kc[i] = a.cam_K ? a.cam_K[(size_t)env * 9 + i] : cam.K[i];
+    for (int i = 0; i < 9; i++) Kc[i] = a.cam_K[(size_t)env * 9 + i];
+  } else {
+    const __attribute__((address_space(4))) double* kk = (const __attribute__((address_space(4))) double*)(unsigned long long)cam.K;
+#pragma unroll
+    for (int i = 0; i < 9; i++) Kc[i] = kk[i];  // (explicitly the kernarg segment: cannot be merged with the other branch)
+  }
   // the 12 entries are the same in every lane: kept in scalar registers through the node loop (24 VGPRs less)
 #pragma unroll
   for (int i = 0; i < 12; i++) pose[i] = uni_d(pose_in[i]);
@@ -1310,6 +1322,8 @@ struct RCam {
   int H, W, wpr, band_rows, n_bands, thickness, format;
   int cap_r;                  // round-cap radius of ThickLine: (thickness*32768 + 32768) >> 16
   unsigned char cap_hw[32];   // half width of the cap per |row offset| (midpoint circle of drawing.cpp)
+  unsigned int cap_hw4;       // cap_hw[0..3] packed, for radii <= 3 (thickness <= 6): a scalar, where indexing the table
+                              // is a vector load from the kernarg segment per cap row (three dependent ~1 us loads per frame)
 };
 struct RArgs {
   int N, C;
@@ -1560,7 +1574,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
           const int cx = (t & 1) ? sg[3] : sg[1], cy = (t & 1) ? sg[4] : sg[2];
           if (cam.n_bands > 1 && ((long long)cy + cam.cap_r < y0 || (long long)cy - cam.cap_r >= y1)) continue;  // cap outside the band
           if (cam.cap_r < 32)
-            r_cap(r, cx, cy, cam.cap_r, cam.cap_hw);
+            r_cap(r, cx, cy, cam.cap_r, cam.cap_hw, cam.cap_hw4);
           else
             r_circle_fill(r, cx, cy, cam.cap_r);
         }
@@ -2466,7 +2480,10 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
       double pose[12];
       cam_pose12(sa.a, env, fp, pose);
       cam_body<K>(sa.a, smem, env, pose, mc, sa.mode != MODE_RENDER, tid, 0, nseg, used);  // (tc_render skips phase B's fetch)
-      __syncthreads();  // draw list written by this wavefront is visible to it (vmcnt(0) + barrier)
+      if (nseg > sa.a.seg_lds_cap)
+        __syncthreads();  // draw-list entries that went through global memory are visible to this wavefront (vmcnt(0) + barrier)
+      else
+        lds_sync();
       const StepArgs& sb = step_args();
       const size_t obs_step = sb.ma.roll.obs ? (size_t)sb.a.N * ((size_t)sb.r.cam.H * sb.r.cam.W * (FMT == TC_FMT_CLASSES ? sb.r.C : 3)) : 0;
       unsigned char* obs_base = sb.ma.roll.obs ? sb.ma.roll.obs : sb.r.obs;
@@ -2551,6 +2568,7 @@ struct tc_env {
   int chunk;        // K-step calls with a rollout: steps per simulate launch when the call is pipelined (TC_CHUNK, 0 = off)
   hipStream_t frame_stream, frame_stream2;
   hipEvent_t sim_ev, frames_ev, frames_ev2;
+  int step_lds;  // tc_step_kernel: LDS bytes per workgroup (lds.total grown like frame_lds)
   int frame_lds, seg_lds_off, seg_lds_cap;  // tc_frame_kernel: LDS bytes per workgroup, draw-list region (see KArgs)
   int frame_streams;  // short K-step calls: frame launches of consecutive chunks alternate between two streams (TC_FRAME_STREAMS)
   int prof_piped[TC_PROF_RING];
@@ -2995,13 +3013,13 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
     int grown = cu_lds / w / 1280 * 1280;
     if (grown > L.total + 4096) grown = L.total + 4096;  // (200 segments are plenty)
     if (grown < L.total) grown = L.total;
-    e->frame_lds = grown;
+    e->frame_lds = e->step_lds = grown;
     e->seg_lds_off = L.off_live;
     e->seg_lds_cap = (grown - L.off_live) / 20;
     if (const char* sl = getenv("TC_SEG_LDS")) {
       if (atoi(sl) == 0) {
         e->seg_lds_cap = 0;
-        e->frame_lds = L.total;
+        e->frame_lds = e->step_lds = L.total;
       }
     }
   }
@@ -3392,6 +3410,7 @@ static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_c
       }
     }
   }
+  r.cam.cap_hw4 = r.cam.cap_hw[0] | (r.cam.cap_hw[1] << 8) | (r.cam.cap_hw[2] << 16) | ((unsigned)r.cam.cap_hw[3] << 24);
   memcpy(r.colors, e->k.m.colors, sizeof(r.colors));
   r.seg_g = seg_g;
   r.seg_n = seg_n;
@@ -3687,7 +3706,11 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     KArgs k = e->k;
     k.env0 = 0;
     RArgs r = make_rargs(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, nullptr, flags, 0, nullptr, mode == MODE_STEP);
-    const int lds = e->k.lds.total;  // covers both stages and the parked state
+    // covers both stages and the parked state; behind it, up to the size that costs the CU no workgroup, the head of the
+    // frame's draw list (see tc_env_create)
+    const int lds = e->step_lds;
+    k.seg_lds_off = r.seg_lds_off = e->k.lds.total;
+    k.seg_lds_cap = r.seg_lds_cap = e->seg_lds_cap ? (e->step_lds - e->k.lds.total) / 20 : 0;
     StepArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.a = k;
