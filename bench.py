@@ -19,12 +19,20 @@ Workloads (BASELINE.json configs):
     cfg5            8192 envs, knuffingen, 480x640 'rgb'
 Envs are sharded over ranks with no data-path collective (they are independent): `value` is the un-gathered rate.  With
 --gpus > 1 the optional exchange step (rewards / flags, and observations, to rank 0 over RCCL) is measured after the
-main region in the same process and reported beside it as `gathered` (separate numbers).
+main region in the same process and reported beside it as `gathered` (separate numbers).  A plain
+`python bench.py --gpus N` (no WORLD_SIZE in the environment) starts its own N ranks as a child
+`python -m torch.distributed.run` before anything touches a GPU and exits with the child's code.
+`value` is the open-loop K-step form (tc_step_multi, actions of a call known in advance); the closed-loop form -- one
+tc_step launch per step, what a policy in the loop sees -- is timed in the same run and reported beside it as
+`value_single_step`.  `config` says what the timed frames drew (mean draw-list length, empty-frame fraction, steps
+since the last re-spawn).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,7 +44,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 B_STATE = 240          # algorithmic state/action/info bytes per env-step
-PROFILE_ROUND = "r02"  # profiles/<round>/<workload>_pmc.json holds the committed PMC summary of this command
+PROFILE_ROUND = "r03"  # profiles/<round>/<workload>_pmc.json holds the committed PMC summary of this command
 
 WORKLOADS = {
     "cfg2": dict(map="simple_layout", res=[64, 64], fmt="classes", envs=4096, no_obs=True),
@@ -170,16 +178,31 @@ def main():
                     help="diagnostic: K-step launches without per-step rollout rows (only the last step's outputs and frame "
                          "are stored; NOT the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-step", action="store_true", help="skip the closed-loop tc_step measurement (value_single_step)")
+    ap.add_argument("--on-road", action="store_true",
+                    help="diagnostic: a two-sided CTE termination term (|cte| > 10 track widths, wrapper/termination.py:24-48) so "
+                         "that cars which drift off the road re-spawn instead of driving through empty scenery for ever "
+                         "(the default env terminates on one side only, env.py:99); NOT the metric's workload")
     ap.add_argument("--cpu-budget", type=int, default=2000000, help="env-steps of the all-cores CPU baseline sample")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as a plain `python bench.py --gpus N`: start the N ranks ourselves, as a FRESH CHILD (never an exec: this
+        # process has imported torch; nothing has touched a GPU yet), and leave with its exit code
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env_c = dict(os.environ)
+        env_c.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env_c).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     # rehearsal knobs for a one-GPU box: TC_BENCH_BACKEND=gloo TC_BENCH_ONE_GPU=1 lets several ranks share cuda:0
     backend = os.environ.get("TC_BENCH_BACKEND", "nccl")
     if os.environ.get("TC_BENCH_ONE_GPU") == "1":
@@ -211,6 +234,10 @@ def main():
         M = 2 if args.workload == "cfg5" else 128
     env = TinyCarloVecEnv(cfg, num_envs=n, device=device, autoreset=True, spawn_queue_len=64)
     env.no_observation = w["no_obs"]
+    if args.on_road:
+        from tinycarlo_amd import terms as T
+        env.wrapped = True  # (the reference's wrappers switch the default reward / termination off, env.py:56,137-138)
+        env.set_terms([T.cte_linear_reward(10 * env.car.track_width, 1.0, 0.0), T.cte_termination(10 * env.car.track_width, 1)])
     env.reset(seed=shard_seed(0, rank, n))  # env i of rank r is the reference env seeded r*n + i
     K, W = args.steps, args.warmup
     period = min(max(K + W, 64), 1024)  # distinct action batches kept in HBM (reused cyclically beyond that)
@@ -224,6 +251,26 @@ def main():
         roll = env.alloc_rollout(M, keys=("obs", "reward", "terminated", "truncated"))
     elif M >= 1:
         roll = env.alloc_rollout(M, keys=("reward", "terminated", "truncated"))
+    if M > 1 and not w["no_obs"]:
+        env.reserve_steps(M)  # the library's scratch ring: allocated here, never inside a call
+    # steps since each env's last re-spawn (workload descriptor): a re-spawn happens in the step AFTER a step that ended
+    # with terminated | truncated.  Kept up to date between the untimed calls; the timed region only writes its flag
+    # rows (into buffers that hold the whole region) and is folded in afterwards.
+    age = torch.zeros(n, dtype=torch.int64, device=device)
+    pend = torch.zeros(n, dtype=torch.bool, device=device)   # env ended its last step with terminated | truncated
+    flag_rows = None
+
+    def fold_flags(term, trunc):
+        """advance `age` / `pend` over the steps whose flag rows are given ([k, n] each)"""
+        nonlocal age, pend
+        done = (term | trunc).bool()
+        k = done.shape[0]
+        # step j re-spawns env i iff the previous step (or `pend` for j = 0) ended done
+        respawn = torch.cat([pend[None], done[:-1]], dim=0)
+        idx = torch.arange(k, device=device)[:, None].expand(k, n)
+        last = torch.where(respawn, idx, torch.full_like(idx, -1)).max(dim=0).values
+        age = torch.where(last >= 0, (k - 1 - last).to(torch.int64), age + k)
+        pend = done[-1].clone()
 
     def issue(t0, cnt, sink=None, m=None):
         """steps t0 .. t0+cnt-1 of the action stream, m per launch (default: M); returns the number of launches"""
@@ -247,7 +294,12 @@ def main():
                     sink.launch(cc[i:i + kk], man[i:i + kk])
                 else:
                     r = None if roll is None else (roll if kk == M else {k_: v[:kk] for k_, v in roll.items()})
+                    if r is not None and flag_rows is not None:  # timed region: flag rows of every step are kept
+                        f0 = t - flag_rows["t0"]
+                        r = dict(r, terminated=flag_rows["terminated"][f0:f0 + kk], truncated=flag_rows["truncated"][f0:f0 + kk])
                     env.step_multi(cc[i:i + kk], man[i:i + kk], rollout=r)
+                    if r is not None and flag_rows is None:
+                        fold_flags(r["terminated"], r["truncated"])
                 t += kk
                 want -= kk
                 nl += 1
@@ -287,16 +339,46 @@ def main():
             issue(preroll % period, chunk)
             preroll += chunk
             torch.cuda.synchronize()
+            env.top_up_spawn_queue()  # the seeded spawn streams continue past what the kernel consumed (never wraps)
     issue(0, W)
+    env.top_up_spawn_queue()
+    age_start = float(age.double().mean().item()) if (M >= 1 and roll is not None) else None
+    if M >= 1 and roll is not None:
+        flag_rows = {"t0": None, "terminated": torch.zeros((K, n), dtype=torch.uint8, device=device),
+                     "truncated": torch.zeros((K, n), dtype=torch.uint8, device=device)}
     # HIP events on the launch stream around the kernel(s) of sampled launches (every launch of a short run; an
     # event triple on every launch of a long one serialises the queue)
     n_launch = K if M == 0 else -(-K // M)
     env.profile(1 if n_launch <= 64 else max(1, n_launch // 48))
     # the timed region starts on a call boundary of the cyclic action buffer, so that no call is split at its wrap-around
     t_start = W if M == 0 else (-(-W // M) * M) % period
+    if flag_rows is not None:
+        flag_rows["t0"] = t_start
     dt, ev_ms, n_l = timed(t_start, K)
     prof = env.profile_read()
     env.profile(0)
+    drew = env.draw_list_stats() if not w["no_obs"] else None  # what the last frames of the timed region drew
+    age_end = None
+    if flag_rows is not None:
+        fr, flag_rows = flag_rows, None
+        fold_flags(fr["terminated"], fr["truncated"])
+        age_end = float(age.double().mean().item())
+        del fr
+    n_resets = int(env._aux["spawn_cursor"].sum().item())
+    max_cursor = int(env._aux["spawn_cursor"].max().item())
+
+    # --- the closed-loop form: one tc_step launch per step (what a policy in the loop sees), same bracket, same run
+    single = None
+    if M >= 1 and not args.no_single_step:
+        K1 = min(K, 256)
+        env.top_up_spawn_queue()
+        issue(0, min(W, 16), m=0)
+        dt1, ev1_ms, _ = timed(0, K1, m=0)
+        single = {"value": world * n * K1 / dt1, "unit": "env-steps/s", "steps": K1, "ms_per_step": dt1 / K1 * 1e3,
+                  "entry_point": "tc_step (one launch per step, closed loop)", "kernel": env.launch_info(1)["kernel"],
+                  "step_frac": (B_STATE + (0 if w["no_obs"] else env.obs_bytes_per_env)) * n / (ev1_ms / 1e3 / K1) / 1e9 / HBM_PEAK_GBS}
+        if not w["no_obs"]:
+            single["drew"] = env.draw_list_stats()
 
     # --- the optional exchange step, measured after the main region (never inside `value`)
     gathered = None
@@ -325,8 +407,6 @@ def main():
         gathered["note"] = ("torch.distributed.gather to rank 0, double-buffered: the gather of launch i overlaps "
                             "launch i+1 (tinycarlo_amd/distributed.py)")
 
-    n_resets = int(env._aux["spawn_cursor"].sum().item())
-    max_cursor = int(env._aux["spawn_cursor"].max().item())
     C = env.n_classes
     H, Wd = env.camera.resolution
     b_obs = 0 if w["no_obs"] else (C * H * Wd if w["fmt"] == "classes" else 3 * H * Wd)
@@ -386,12 +466,29 @@ def main():
                                      else "every step's frame stored to the bound buffer")),
                    "launches_timed": n_l, "preroll_steps": preroll,
                    "actions": "v~U(0.3,1) s~U(-1,1) maneuver~U{0..3}/64 steps, on device",
-                   "autoreset": True, "spawn": "host queue (reference seed parity)", "resets_in_run": n_resets,
-                   "max_respawns_of_one_env": max_cursor, "spawn_queue_len": env.spawn_queue_len,
+                   "autoreset": True,
+                   # the queue is topped up between the untimed calls; inside the timed region it may only be consumed
+                   "spawn": ("host queue (reference seed parity)" if max_cursor < env.spawn_queue_len else
+                             "host queue, WRAPPED inside the timed region (spawn nodes replayed: no seed parity)"),
+                   "resets_in_timed_region": n_resets, "max_respawns_of_one_env_in_timed_region": max_cursor,
+                   "spawn_queue_len": env.spawn_queue_len,
+                   # what the timed frames drew: draw lists of the last <= 3 dispatches of the timed region
+                   "mean_segments_per_frame": drew["mean_segments_per_frame"] if drew else None,
+                   "empty_frame_frac": drew["empty_frame_frac"] if drew else None,
+                   "max_segments_per_frame": drew["max_segments"] if drew else None,
+                   "frames_sampled": drew["frames"] if drew else None,
+                   "steps_since_reset_mean": {"timed_region_start": age_start, "timed_region_end": age_end},
+                   "on_road_term": bool(args.on_road),
                    "lds_bytes_per_env": env.lds_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": dom, "kernel_us": kernel_s * 1e6, "steps_per_dispatch": rows_per_dispatch,
+                     "kernel": dom, "kernel_us": kernel_s * 1e6,
+                     "kernel_us_is": ("HIP-event span of the call's frame dispatches / number of dispatches"
+                                      + (" (consecutive dispatches alternate between two internal streams and overlap: "
+                                         "a span per dispatch, not one dispatch's duration)" if (two and spd < 8 and n_disp > 1) else
+                                         " (one stream, back to back: the average dispatch duration)") if two else
+                                      "HIP-event duration of the launch"),
+                     "steps_per_dispatch": rows_per_dispatch,
                      "dispatches_per_call": n_disp, "steps_per_call": steps_in_sampled,
                      "kernel_us_per_step": kernel_s * 1e6 / rows_per_dispatch,
                      "algorithmic_bytes_per_launch": kbytes, "algorithmic_bytes_per_unit": dom_bytes_per_frame,
@@ -404,6 +501,10 @@ def main():
                      "step_us": step_s * 1e6, "step_achieved_GBs": bytes_per_env_step * n / step_s / 1e9,
                      "step_frac": bytes_per_env_step * n / step_s / 1e9 / HBM_PEAK_GBS},
     }
+    if single is not None:
+        out["value_single_step"] = single
+        out["entry_points"] = {"value": "tc_step_multi: K-step calls, the actions of a call known in advance (open loop)",
+                               "value_single_step": "tc_step: one launch per step (closed loop)"}
     if gathered is not None:
         out["gathered"] = gathered
     if rank == 0:

@@ -21,9 +21,15 @@
  *     (e.g. torch tensors); the library stores the pointers given to tc_env_bind and never frees them.
  *   - every pointer inside tc_buffers, and the action pointers of tc_step / tc_reset, are DEVICE
  *     pointers on the device that was current at tc_map_create time.
- *   - kernels are enqueued on the hipStream_t passed as `stream` (void*, NULL = default stream);
- *     no call synchronises the device except tc_map_create / tc_env_create / tc_*_destroy.
- *   - one host thread per env handle at a time.
+ *   - kernels are enqueued on the hipStream_t passed as `stream` (void*, NULL = default stream) and complete in
+ *     stream order; tc_reset / tc_step / tc_step_multi / tc_render* / tc_noise neither allocate nor synchronise
+ *     (they can be captured into a HIP graph).  The calls that DO wait for the device: tc_map_create,
+ *     tc_env_create, tc_env_reserve_steps (when it has to re-allocate), tc_env_set_terms, tc_env_set_noise,
+ *     tc_env_set_spawn_table, tc_env_profile_read and the destroy calls.
+ *   - one host thread per env handle at a time, and ONE STREAM AT A TIME per handle: the library-owned scratch of a
+ *     handle (draw lists, pose rows) is reused by consecutive calls, which is safe because they follow each other in
+ *     stream order.  A K-step call issued on a different stream than the handle's previous K-step call is ordered
+ *     behind it by the library (an event wait); for every other combination of streams the caller orders them.
  *   - every function returns 0 on success or a negative TC_E_* code; nothing throws.
  *   - arithmetic is IEEE double like the reference (python floats / numpy float64); pixel
  *     coordinates are int32, observations uint8.
@@ -38,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 4
+#define TC_ABI_VERSION 5
 #define TC_MAX_LAYERS 16
 
 /* error codes */
@@ -230,25 +236,41 @@ int tc_reset(tc_env* env, const int32_t* spawn_nodes, const uint8_t* mask, uint3
 int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const int32_t* maneuver, uint32_t flags,
             void* stream);
 
-/* K steps in ONE launch: the caller's `for k in range(K): env.step(action[k])` loop (env.py:115-147 called K times,
+/* K steps in ONE call: the caller's `for k in range(K): env.step(action[k])` loop (env.py:115-147 called K times,
  * e.g. examples/stanley_control.py:50-60 with the actions known in advance: action repeat, open-loop rollouts,
- * scripted policies).  One wavefront stays with its env for all K steps -- envs are independent, so no grid-wide
- * synchronisation exists between steps -- and keeps the env's state on chip in between.
+ * scripted policies).  Envs are independent, so no grid-wide synchronisation exists between steps.
  *   car_control: [K][N][2], maneuver: [K][N] (step k uses row k).
  *   Results are bit-identical to K calls of tc_step with the same flags: the bound buffers (tc_env_bind) hold the
- *   state and the outputs of step K-1 afterwards; TC_F_AUTORESET re-spawns and fused terms (tc_env_set_terms) act
- *   per step exactly as there.
- *   rollout (may be NULL): per-step copies of the outputs a learner reads, each [K][N] (obs: [K][N][obs_bytes]) or
- *   NULL.  With rollout->obs the observation of step k goes to rollout->obs[k] and the bound obs buffer is left
- *   untouched; without it every step stores its observation into the bound buffer (which ends up holding the last).
- * Launches: a simulate launch that loops over the steps and, when observations are rendered, a launch of steps x N
- * workgroups over the frames (camera + raster of one frame each; without rollout->obs only the last step's frame is
- * drawn: the others would be overwritten).  With rollout->obs the call is issued in chunks of 16 steps (a quarter of
- * the call if that is less): the frames of chunk c are produced on an internal stream while chunk c+1 is simulated on
- * the caller's, and the internal stream is joined back before the call's work on the caller's stream ends, so
- * everything still completes in stream order.  Env vars: TC_CHUNK=0 no pipelining, TC_ENV_GROUPED=0 one wavefront per
- * env in the simulate launch, TC_MULTI_SPLIT=0 a single fused launch in which the same wavefront simulates its env and
- * rasterises each of its frames. */
+ *   state and the outputs of step K-1 afterwards (status included: the TC_S_* bits of step K-1 only -- the per-step
+ *   bits are in rollout->status); TC_F_AUTORESET re-spawns and fused terms (tc_env_set_terms) act per step exactly
+ *   as there.
+ *   rollout (may be NULL): per-step copies of everything env.step() returns (env.py:83-85,131-147), each member
+ *   [K][N] (shapes below) or NULL.  With rollout->obs the observation of step k goes to rollout->obs[k] and the
+ *   bound obs buffer is left untouched; without it every step stores its observation into the bound buffer (which
+ *   ends up holding the last).
+ * What is launched (tc_env_launch_info reports it):
+ *   - no observation wanted: ONE launch of tc_env_kernel, one wavefront per env looping over the K steps with the
+ *     env's state parked in LDS.
+ *   - observations: the steps are issued in chunks of at most 16 steps (a quarter of the call if that is less).  Per
+ *     chunk a SIMULATE launch -- tc_envg_kernel: 8 lanes per env, 8 envs per wavefront, state in registers, looping
+ *     over the chunk's steps and leaving one 128-byte pose row (camera.py:62) per (step, env); the first chunk of a
+ *     multi-chunk call goes through tc_env_kernel instead (short rather than cheap: nothing overlaps it) -- and a
+ *     FRAME launch -- tc_frame_kernel: one workgroup per (step, env) of the chunk, camera stage + raster stage + the
+ *     observation store.  With rollout->obs the frame launches run on an internal stream behind their chunk's simulate
+ *     launch, so chunk c+1 is simulated while chunk c is drawn; the internal stream is joined back into the caller's
+ *     before the call's work there ends, so everything still completes in stream order.  Calls whose chunks are
+ *     shorter than 8 steps alternate their frame launches between two internal streams.  Without rollout->obs only
+ *     the last step's frame is drawn (the others would be overwritten).
+ *   - maps whose largest lane-line layer exceeds 576 nodes / edges (K = 13 variant) and TC_FUSE=0: the camera stage
+ *     runs inside the simulate launch and tc_raster_kernel draws the frames.
+ * The pose rows and draw lists of the chunks in flight live in a library-owned ring sized by tc_env_reserve_steps,
+ * which must have been called once before the first K-step call that renders (n_steps > 1 with an observation):
+ * tc_step_multi itself never allocates and never waits for the device; without a ring it returns TC_E_INVALID.
+ * Env vars (all result-neutral, read at tc_env_create): TC_CHUNK=n steps per chunk (0: chunks follow each other on
+ * the caller's stream, no overlap), TC_ENV_GROUPED=0 one wavefront per env in every simulate launch,
+ * TC_FIRST_CHUNK_PER_ENV=0, TC_FRAME_STREAMS=1, TC_ENVG_MAP_LDS=0, TC_MULTI_SPLIT=0 a single fused launch in which
+ * the same wavefront simulates its env and rasterises each of its frames, TC_SEG_LDS=0 / TC_SEG_LDS_CAP=n draw lists
+ * through global memory only / beyond the first n segments. */
 typedef struct {
   uint8_t* obs;          /* [K][N][tc_env_obs_bytes] */
   double* reward;        /* [K][N] */
@@ -256,9 +278,24 @@ typedef struct {
   uint8_t* truncated;    /* [K][N] */
   double* cte;           /* [K][N] */
   double* heading_error; /* [K][N] */
+  /* --- ABI 5: the rest of env.step()'s info dict (env.py:83-85) and the status bits, per step */
+  int32_t* status;             /* [K][N] TC_S_* bits raised in step k */
+  double *x, *y, *theta;       /* [K][N] info["position"], info["orientation"] (state after step k) */
+  double* velocity;            /* [K][N] car velocity after step k (info["velocity"] is this, or 0 while lp_len < 2) */
+  double* laneline_distances;  /* [K][N][n_layers] */
+  int32_t* nearest_edge;       /* [K][N][n_layers] */
+  int32_t* local_path;         /* [K][N][8] */
+  int32_t* lp_len;             /* [K][N] */
 } tc_rollout;
 int tc_step_multi(tc_env* env, const void* car_control, int32_t control_dtype, const int32_t* maneuver, int32_t n_steps,
                   uint32_t flags, const tc_rollout* rollout, void* stream);
+
+/* Sizes the scratch ring of K-step calls that render observations: TC_RING_SLOTS (3) chunks of min(max_chunk_steps,
+ * 16 or TC_CHUNK) steps x N envs of pose rows (128 B) and draw lists (20 B x lane-line edges of the map; only a
+ * frame's overflow beyond the LDS-resident head travels through them).  A call of ANY n_steps then runs in chunks
+ * that fit the ring.  Re-allocating waits for the device first (an earlier launch may still read the old ring); a
+ * request the current ring already covers returns at once.  max_chunk_steps < 1 is TC_E_INVALID. */
+int tc_env_reserve_steps(tc_env* env, int32_t max_chunk_steps);
 
 /* What the library launches for a call of n_steps steps (1 = tc_step) with the current settings -- for benchmark
  * labels, not for control flow: fused = 1 when simulate + raster run as one kernel; kvar = register-cache variant of
@@ -268,6 +305,11 @@ int tc_step_multi(tc_env* env, const void* car_control, int32_t control_dtype, c
  * at most name_cap bytes including the terminator. */
 int tc_env_launch_info(const tc_env* env, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar,
                        int32_t* steps_per_dispatch, char* name, int32_t name_cap);
+
+/* Workload descriptor for benchmark lines -- what the most recent frames drew: mean / max length of the frames' draw
+ * lists (segments handed to cv2.polylines, camera.py:95-106) and the fraction of frames with none, over the N frames of
+ * the last tc_step or the frames of the last (up to 3) chunks of the last tc_step_multi call.  Waits for the device. */
+int tc_env_draw_list_stats(tc_env* env, double* mean_segments, double* empty_frac, int32_t* max_segments, int64_t* frames);
 
 /* Renderer.render_camera_frame_{rgb,classes} alone (renderer.py:36-51): rasterise caller-provided segment lists
  * into the bound observation tensor.  segments: device int32 [N][capacity][5] rows of (layer, x0, y0, x1, y1) --

@@ -120,6 +120,7 @@ class OracleVecEnv(TinyCarloVecEnv):
         self._rerender_env_cams()
         self._keep = (torch.as_tensor(np.asarray(spawn_nodes, dtype=np.int32)), mask)
         self._was_reset = True
+        self._step_serial += 1
 
     def step_device(self, car_control, maneuver):
         if not self._was_reset:
@@ -132,6 +133,7 @@ class OracleVecEnv(TinyCarloVecEnv):
         self._rerender_env_cams()
         if self.noise[0] and not no_obs:
             self._apply_noise()
+        self._step_serial += 1
 
     def step_multi(self, car_control, maneuver, rollout=None):
         """TinyCarloVecEnv.step_multi on the oracle: K single steps, per-step outputs copied into the rollout rows;
@@ -141,7 +143,7 @@ class OracleVecEnv(TinyCarloVecEnv):
         for k in range(K):
             self.step_device(car_control[k], maneuver[k])
             for key, t in (rollout or {}).items():
-                t[k].copy_(self.out[key])
+                t[k].copy_(self.out[key] if key in self.out else self.state[key])
         if keep is not None:
             self.out["obs"].copy_(keep)
 

@@ -299,3 +299,71 @@ def test_reset_to_accepts_tensor_masks():
         e.reset_to(nodes, mask=mk)
         assert e.state["local_path"][:, 0].tolist()[0] == int(nodes[0]) == e.state["local_path"][:, 0].tolist()[3]
         assert torch.equal(e.state["x"][1:3], before["x"][1:3])
+
+
+def test_vec_info_is_a_dict_with_lazy_entries_and_stale_reads_raise():
+    """step() returns a real dict (gymnasium's PassiveEnvChecker: isinstance(info, dict); wrappers write
+    info[...]); derived entries are listed like the others, built on first access, and a derived entry first read
+    after the env has stepped again raises instead of silently describing the later step (env.py:83-85)."""
+    env = OracleVecEnv(cfg_for("simple_layout"), num_envs=4)
+    env.reset(seed=0)
+    act = {"car_control": np.tile(np.array([[0.8, 0.1]], dtype=np.float32), (4, 1)), "maneuver": np.zeros(4, dtype=np.int32)}
+    for _ in range(3):
+        _, _, _, _, info = env.step(act)
+    assert isinstance(info, dict)
+    want = {"cte", "heading_error", "position", "orientation", "laneline_distances", "local_path", "local_path_len",
+            "velocity", "status"}
+    assert set(info) == want and set(info.keys()) == want and len(info) == len(want) and "position" in info
+    assert info.get("position").shape == (4, 2) and info.get("nope", 7) == 7
+    info["my_wrapper_key"] = 1.0                       # wrappers may add entries
+    assert "my_wrapper_key" in info and len(info) == len(want) + 1
+    assert dict(info.items())["velocity"].shape == (4,)
+    snap = info.materialize()
+    pos_before = snap["position"].clone()
+    _, _, _, _, info_old = env.step(act)               # not touched before the next step ...
+    _, _, _, _, info_new = env.step(act)
+    with pytest.raises(RuntimeError):
+        info_old["position"]                           # ... so this would describe the later step: refused
+    assert torch.equal(snap["position"], pos_before) and not torch.equal(info_new["position"], pos_before)
+    with pytest.raises(KeyError):
+        info_new["no_such_key"]
+
+
+def test_vec_rollout_info_equals_step_info():
+    """step_multi's info rows (ABI 5) give, per step, the info dict step() returns after that step (env.py:83-85)"""
+    a = OracleVecEnv(cfg_for("simple_layout"), num_envs=6, autoreset=True)
+    b = OracleVecEnv(cfg_for("simple_layout"), num_envs=6, autoreset=True)
+    a.reset(seed=3)
+    b.reset(seed=3)
+    rng = np.random.default_rng(0)
+    K = 12
+    cc = torch.from_numpy(np.stack([rng.uniform(0.3, 1, (K, 6)), rng.uniform(-1, 1, (K, 6))], axis=2).astype(np.float32))
+    man = torch.from_numpy(rng.integers(0, 4, (K, 6)).astype(np.int32))
+    roll = a.alloc_rollout(K, keys="all")
+    a.step_multi(cc, man, rollout=roll)
+    for k in range(K):
+        _, _, _, _, info = b.step({"car_control": cc[k], "maneuver": man[k]})
+        ri = a.rollout_info(roll, k)
+        assert set(ri) == set(info)
+        for key in ri:
+            if key == "laneline_distances":
+                for name in ri[key]:
+                    assert torch.equal(ri[key][name], info[key][name]), (k, key, name)
+            else:
+                assert torch.equal(ri[key], info[key]), (k, key)
+
+
+def test_debug_switch_prints_phase_times(monkeypatch, capsys):
+    """DEBUG=1 (helper.py:4-9) makes step() print its phase timings like env.py:144-145; read on every step"""
+    env = OracleVecEnv(cfg_for("simple_layout"), num_envs=2)
+    env.reset(seed=0)
+    calls = []
+    monkeypatch.setattr(env, "profile", lambda every=1: calls.append(every))
+    monkeypatch.setattr(env, "profile_read", lambda: {"simulate_us": 12.0, "raster_us": 3.0, "launches": 1})
+    act = {"car_control": np.zeros((2, 2), dtype=np.float32), "maneuver": np.zeros(2, dtype=np.int32)}
+    env.step(act)
+    assert capsys.readouterr().out == "" and calls == []
+    monkeypatch.setenv("DEBUG", "1")
+    env.step(act)
+    out = capsys.readouterr().out
+    assert out.startswith("step: all: ") and "simulate 0.0120 ms" in out and "frames 0.0030 ms" in out and calls == [1, 0]

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TINYCARLO_HIP_LIB: load another build of the same library (tools/phase_clock.py uses the instrumented one)
 LIB_PATH = os.environ.get("TINYCARLO_HIP_LIB") or os.path.join(_HERE, "libtinycarlo_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_TERMS, MAX_LAYERS = 8, 16
 FMT_RGB, FMT_CLASSES = 0, 1
 F32, F64 = 0, 1
@@ -27,7 +27,7 @@ S_UTURN_NO_EDGE, S_PICK_EMPTY, S_BAD_SPAWN, S_NOT_RESET, S_SPAWN_WRAPPED = 1, 2,
 
 EXPORTS = ["tc_abi_version", "tc_last_error", "tc_map_create", "tc_map_destroy", "tc_env_create", "tc_env_destroy",
            "tc_env_bind", "tc_env_set_camera", "tc_env_set_camera_per_env", "tc_env_set_terms", "tc_env_set_spawn_table", "tc_env_set_noise", "tc_noise", "tc_env_obs_bytes", "tc_env_lds_bytes", "tc_env_profile",
-           "tc_env_profile_read", "tc_reset", "tc_step", "tc_step_multi", "tc_env_launch_info", "tc_render",
+           "tc_env_profile_read", "tc_reset", "tc_step", "tc_step_multi", "tc_env_reserve_steps", "tc_env_launch_info", "tc_env_draw_list_stats", "tc_render",
            "tc_render_segments"]
 
 _dp, _ip, _bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
@@ -59,7 +59,9 @@ class Buffers(C.Structure):
 
 
 class Rollout(C.Structure):  # tc_rollout: per-step outputs of tc_step_multi, each [K][N] (obs [K][N][obs_bytes]) or NULL
-    _fields_ = [(n, C.c_void_p) for n in ("obs", "reward", "terminated", "truncated", "cte", "heading_error")]
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "reward", "terminated", "truncated", "cte", "heading_error", "status",
+                                          "x", "y", "theta", "velocity", "laneline_distances", "nearest_edge",
+                                          "local_path", "lp_len")]
 
 
 class TermC(C.Structure):  # tc_term
@@ -126,6 +128,9 @@ def lib():
     L.tc_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.tc_step_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint32,
                                 C.POINTER(Rollout), C.c_void_p]
+    L.tc_env_reserve_steps.argtypes = [C.c_void_p, C.c_int32]
+    L.tc_env_draw_list_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int64)]
     L.tc_env_launch_info.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), C.c_char_p, C.c_int32]
     L.tc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]

@@ -12,6 +12,12 @@ import yaml
 DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 
+def getenv(key: str) -> bool:
+    """helper.py:4-9: an environment switch is on when its value is "1"."""
+    v = os.environ.get(key)
+    return v is not None and v.lower() == "1"
+
+
 def load_config(config: Union[str, Dict[str, Any]]) -> Tuple[Dict[str, Any], Optional[str]]:
     """Returns (config dict, path of the yaml it came from or None) -- env.py:26-35."""
     path = None

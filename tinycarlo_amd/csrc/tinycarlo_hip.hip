@@ -94,7 +94,7 @@ __device__ long long* tc_tstamp = nullptr;  // [N][32]
 #endif
 
 #define TC_PROF_RING 64
-#define TC_MAX_SPLIT 8
+#define TC_RING_SLOTS 3  // chunks of a K-step call whose pose rows / draw lists exist at once (tc_env_reserve_steps)
 #define MODE_STEP 0
 #define MODE_RESET 1
 #define MODE_RENDER 2
@@ -113,7 +113,6 @@ __device__ long long* tc_tstamp = nullptr;  // [N][32]
 #define DBG_SKIP_QUAD 0x80000u
 #define DBG_SKIP_CLIP 0x100000u
 #define DBG_SKIP_DRAWLIST 0x200000u
-#define RF_ZERO_FIRST 0x1000000u  // raster stage, rgb: zero the whole frame before the first band (TC_RGB_ZERO_FIRST=1)
 // the kernels test them only in the ablation build (make dev-ablate): in the shipped library every test folds to false,
 // so the switches cost no scalar registers there (they were ~25 live conditions at the head of the raster stage)
 #ifdef TC_ABLATE
@@ -177,6 +176,12 @@ static_assert(sizeof(LiveLds) <= TC_LIVE_BYTES, "LiveLds must fit its LDS slot")
 struct RollStep {
   double *reward, *cte, *heading_error;
   unsigned char *terminated, *truncated;
+  int* status;
+  double *x, *y, *theta, *velocity;
+  double* dist;  // [N][C]
+  int* ne;       // [N][C]
+  int* lp;       // [N][8]
+  int* lp_len;
 };
 
 struct KArgs {
@@ -931,6 +936,12 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
       if (roll.cte) roll.cte[env] = cte;
       if (roll.heading_error) roll.heading_error[env] = he;
       if (roll.truncated) roll.truncated[env] = (unsigned char)trunc;
+      if (roll.status) roll.status[env] = status;
+      if (roll.x) roll.x[env] = s.x;
+      if (roll.y) roll.y[env] = s.y;
+      if (roll.theta) roll.theta[env] = s.theta;
+      if (roll.velocity) roll.velocity[env] = s.velocity;
+      if (roll.lp_len) roll.lp_len[env] = s.lp_len;
       if (!late) {
         lv->reward = reward;
         lv->terminated = terminated;
@@ -944,6 +955,7 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
 #pragma unroll
       for (int i = 1; i < 8; i++) v = tid == i ? s.lp[i] : v;
       lv->lp[tid] = v;
+      if (roll.lp) roll.lp[(size_t)env * 8 + tid] = v;
     }
 
     TSTAMP(2);
@@ -1065,12 +1077,16 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
         }
         lv->dist[l] = dist_l;
         lv->ne[l] = my_e;
+        if (roll.dist) roll.dist[(size_t)env * C + l] = dist_l;
+        if (roll.ne) roll.ne[(size_t)env * C + l] = my_e;
       }
       TSTAMP(16);
       __syncthreads();  // dn aliases the camera's node buffer
     } else if (tid < C) {
       lv->dist[tid] = 0;
       lv->ne[tid] = -1;
+      if (roll.dist) roll.dist[(size_t)env * C + tid] = 0;
+      if (roll.ne) roll.ne[(size_t)env * C + tid] = -1;
     }
     if (late) {
       // a re-spawned env did not go through Wrapper.step (the reference's reset() bypasses the wrappers)
@@ -1305,13 +1321,22 @@ struct MultiArgs {
                       // copied into the workgroup's LDS at kernel start and phase B reads them from there
   tc_rollout roll;
 };
-__device__ __forceinline__ RollStep roll_at(const tc_rollout& r, size_t row0) {
+__device__ __forceinline__ RollStep roll_at(const tc_rollout& r, size_t row0, int C) {
   RollStep q;
   q.reward = r.reward ? r.reward + row0 : nullptr;
   q.cte = r.cte ? r.cte + row0 : nullptr;
   q.heading_error = r.heading_error ? r.heading_error + row0 : nullptr;
   q.terminated = r.terminated ? r.terminated + row0 : nullptr;
   q.truncated = r.truncated ? r.truncated + row0 : nullptr;
+  q.status = r.status ? r.status + row0 : nullptr;
+  q.x = r.x ? r.x + row0 : nullptr;
+  q.y = r.y ? r.y + row0 : nullptr;
+  q.theta = r.theta ? r.theta + row0 : nullptr;
+  q.velocity = r.velocity ? r.velocity + row0 : nullptr;
+  q.dist = r.laneline_distances ? r.laneline_distances + row0 * C : nullptr;
+  q.ne = r.nearest_edge ? r.nearest_edge + row0 * C : nullptr;
+  q.lp = r.local_path ? r.local_path + row0 * 8 : nullptr;
+  q.lp_len = r.lp_len ? r.lp_len + row0 : nullptr;
   return q;
 }
 
@@ -1337,9 +1362,11 @@ struct RArgs {
   const unsigned char* mask;  // reset mask (NULL = all envs)
   int off_tab, off_bits;
   unsigned int flags;
-  // raster launches over several steps' frames (grid.y = frames rows): row blockIdx.y reads draw list row seg_row0 +
-  // blockIdx.y and writes its frame obs_row_stride bytes behind the previous row's
+  // raster launches over several steps' frames (grid.y = frames rows): row blockIdx.y reads draw list / pose row
+  // seg_row0 + blockIdx.y of the library's scratch ring, writes its frame obs_row_stride bytes behind the previous
+  // row's, and is step noise_row0 + blockIdx.y of the call (position in the blob stream)
   int seg_row0;
+  int noise_row0;
   long long obs_row_stride;
   // NoiseObservationWrapper fused into the raster stage (class masks only): blobs per plane (0 = off), radius bound,
   // the per-radius span table and the blob stream (position of frame row 0 = *noise_step)
@@ -1405,17 +1432,6 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
   int* fpv = fpy + 4 * RB;                // [RB][4] fill pieces: polygon vertices idx0 | idx << 2
   long long* fpx = (long long*)(fpv + 4 * RB);  // [RB][4] x at the start row (16.16)
   long long* fpd = fpx + 4 * RB;          // [RB][4] dx per row
-  const bool zero_first = (a.flags & RF_ZERO_FIRST) != 0;
-  if (FMT != TC_FMT_CLASSES && (W & 15) == 0 && zero_first) {
-    // rgb: lane lines cover ~1 % of a frame.  The WHOLE frame is written as zeros with coalesced 16-byte stores up
-    // front -- they drain while the bands are rasterised -- and each band then only revisits the pixels that have a bit
-    // set in some plane.  (Zeroing band by band put a wait for the band's zeros in front of its pixel stores: 12-19
-    // store round trips per 480x640 frame with nothing to overlap them.)
-    const int n16 = H * W * 3 / 16;
-    uint4* dst = (uint4*)out;
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    for (int q = tid; q < n16; q += TC_NT) dst[q] = z;
-  }
   for (int band = 0; band < cam.n_bands; band++) {
     const int y0 = band * cam.band_rows;
     const int y1 = (y0 + cam.band_rows < H) ? y0 + cam.band_rows : H;
@@ -1700,16 +1716,16 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
     } else {
       // rgb: painter's order (renderer.py:41-43): the highest layer covering a pixel wins
       if ((W & 15) == 0) {
-        // zeros first (the whole frame before the first band, or this band's rows here), then only the pixels that have
-        // a bit set in some plane; the zeros must be in the memory system before the pixel stores go out (byte stores
-        // into lines this wavefront has written)
-        if (!zero_first) {
+        // this band's rows as zeros first, then only the pixels that have a bit set in some plane; the zeros must be in
+        // the memory system before the pixel stores go out (byte stores into lines this wavefront has written).
+        // (Zeroing the whole frame before the first band was measured: 16 % slower)
+        {
           const int n16 = rows * W * 3 / 16;
           uint4* dst = (uint4*)(out + (size_t)y0 * W * 3);
           const uint4 z = make_uint4(0, 0, 0, 0);
           for (int q = tid; q < n16; q += TC_NT) dst[q] = z;
         }
-        if (band == 0 || !zero_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int nw = rows * wpr;
         for (int q = tid; q < nw; q += TC_NT) {
           unsigned int any = 0;
@@ -1788,7 +1804,7 @@ __global__ __launch_bounds__(TC_NT, TC_RASTER_WAVES) void tc_raster_kernel(RArgs
   // one workgroup per (frame row, env): with more frames than resident workgroups the dispatcher hands the next frame
   // to whichever slot frees up first, so light and heavy frames balance out across the chip
   const size_t slot0 = (size_t)(a.seg_row0 + blockIdx.y) * a.N;
-  raster_body<THICK, FMT>(a, smem, env, a.obs + (size_t)blockIdx.y * a.obs_row_stride, threadIdx.x, slot0, -1, 0u, a.seg_row0 + (int)blockIdx.y);
+  raster_body<THICK, FMT>(a, smem, env, a.obs + (size_t)blockIdx.y * a.obs_row_stride, threadIdx.x, slot0, -1, 0u, a.noise_row0 + (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2039,7 +2055,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? TC_MIN_WAVES : K <= 9 ? 3 : 2)) vo
                           // registers per lane held across the whole step body, raster stage included)
     FramePose fp;
     sim_body<K>(sa.a, smem, env, sa.mode, (const char*)sa.car_control + row0 * 2 * esz, sa.cdtype, sa.maneuver + row0,
-                sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), tid, mc, fp);
+                sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0, sa.a.m.C), tid, mc, fp);
     if (sa.ma.pose_rows) {
       double pose[12];
       cam_pose12(sa.a, env, fp, pose);
@@ -2167,7 +2183,7 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
     const tc_buffers& b = a.b;
     const unsigned int flags = sa.flags;
     const size_t row0 = (size_t)k * a.N;
-    const RollStep roll = roll_at(sa.ma.roll, row0);
+    const RollStep roll = roll_at(sa.ma.roll, row0, a.m.C);
     status = 0;
     trunc = 0;
     TSTAMP(24);
@@ -2322,6 +2338,10 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
             }
           }
           gl.dist[l] = dist_l;
+          if (live) {
+            if (roll.dist) roll.dist[(size_t)env * C + l] = dist_l;
+            if (roll.ne) roll.ne[(size_t)env * C + l] = ne;
+          }
           if (last && live) {
             b.laneline_distances[(size_t)env * C + l] = dist_l;
             b.nearest_edge[(size_t)env * C + l] = ne;
@@ -2332,6 +2352,10 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
     } else {
       for (int l = sub; l < C; l += TC_EL) {  // no info this step (car.py:47-51): zero distances, no nearest edge
         gl.dist[l] = 0;
+        if (live) {
+          if (roll.dist) roll.dist[(size_t)env * C + l] = 0;
+          if (roll.ne) roll.ne[(size_t)env * C + l] = -1;
+        }
         if (last && live) {
           b.laneline_distances[(size_t)env * C + l] = 0;
           b.nearest_edge[(size_t)env * C + l] = -1;
@@ -2351,6 +2375,17 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
       if (roll.truncated) roll.truncated[env] = (unsigned char)trunc;
       if (roll.reward) roll.reward[env] = reward;
       if (roll.terminated) roll.terminated[env] = (unsigned char)terminated;
+      if (roll.status) roll.status[env] = status;
+      if (roll.x) roll.x[env] = s.x;
+      if (roll.y) roll.y[env] = s.y;
+      if (roll.theta) roll.theta[env] = s.theta;
+      if (roll.velocity) roll.velocity[env] = s.velocity;
+      if (roll.lp_len) roll.lp_len[env] = s.lp_len;
+      if (roll.lp) {
+        int4* o = (int4*)(roll.lp + (size_t)env * 8);
+        o[0] = make_int4(s.lp[0], s.lp[1], s.lp[2], s.lp[3]);
+        o[1] = make_int4(s.lp[4], s.lp[5], s.lp[6], s.lp[7]);
+      }
     }
     if (sa.ma.pose_rows) {
       // car.py:159-165 takes cos(-theta), sin(-theta): tc_cos is exactly even and tc_sin exactly odd, so the values of
@@ -2443,7 +2478,8 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame
   else
     lds_sync();
   const FrameArgs& fr = frame_args();
-  raster_body<THICK, FMT>(fr.r, smem, env, fr.r.obs + (size_t)blockIdx.y * fr.r.obs_row_stride, tid, slot0, nseg, used, row);
+  raster_body<THICK, FMT>(fr.r, smem, env, fr.r.obs + (size_t)blockIdx.y * fr.r.obs_row_stride, tid, slot0, nseg, used,
+                          fr.r.noise_row0 + (int)blockIdx.y);
 }
 
 // All stages in one launch: the same wavefront simulates its env, runs the camera and rasterises the frame.  The form
@@ -2473,7 +2509,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
                           // registers per lane held across the whole step body, raster stage included)
     FramePose fp;
     sim_body<K>(sa.a, smem, env, sa.mode, (const char*)sa.car_control + row0 * 2 * esz, sa.cdtype, sa.maneuver + row0,
-                sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0), tid, mc, fp);
+                sa.spawn_nodes, sa.mask, sa.flags, roll_at(sa.ma.roll, row0, sa.a.m.C), tid, mc, fp);
     if (wants_frame(sa)) {
       int nseg;
       unsigned int used;
@@ -2550,12 +2586,6 @@ struct tc_env {
   bool bound;
   int64_t obs_bytes;
   int r_off_tab, r_off_bits, r_lds;
-  // Optional (env var TC_SPLIT=n, default 1 = off): issue a step as n sub-batches of envs, sub-batch 0 on the
-  // caller's stream, the others on internal streams forked from / joined back into it with events, so the
-  // latency-bound simulate kernel of one sub-batch overlaps the issue-bound raster kernel of another.
-  // Measured on MI355X (cfg3): n=1 91.7 us, n=2 106.3 us, n=4 134.2 us -- the event fork/join costs more than
-  // the overlap gains, so it stays off.
-  int split;
   int fuse;  // 1: simulate + raster in one launch (tc_step_kernel); 0: two launches
   // tc_step_multi with observations, split form (default; TC_MULTI_SPLIT=0 selects the fused K-step kernel): ONE
   // simulate launch loops over the K steps and leaves K draw lists per env, ONE raster launch of K x N workgroups
@@ -2564,22 +2594,32 @@ struct tc_env {
   // env (measured on cfg3: 70.9 us per step against a mean of 41 us per wavefront-step).  Frames are independent of
   // each other, and K x N workgroups are many more than the chip holds at once, so the dispatcher balances them.
   int multi_split;
-  int chunk_div;    // a call shorter than chunk_div chunks is cut into chunk_div pieces (TC_CHUNK_DIV, default 4)
-  int chunk;        // K-step calls with a rollout: steps per simulate launch when the call is pipelined (TC_CHUNK, 0 = off)
+  int chunk;        // K-step calls with a rollout: steps per chunk (TC_CHUNK, default 16)
+  int pipe;         // 1: the frame launches of a chunk run on an internal stream beside the next chunk's simulate launch
+                    // (TC_CHUNK=0 switches that off: chunks of the default size follow each other on the caller's stream)
   hipStream_t frame_stream, frame_stream2;
   hipEvent_t sim_ev, frames_ev, frames_ev2;
+  hipEvent_t slot_ev[TC_RING_SLOTS];  // frames of the chunk that last used ring slot s are done
+  hipEvent_t call_ev;                 // end of the last K-step call on its stream
+  hipStream_t last_stream;            // stream of that call
+  bool have_call;
+  // where the draw-list lengths of the most recent frames are (tc_env_draw_list_stats): up to TC_RING_SLOTS (first ring
+  // row, rows) pairs of the last K-step call, or the per-env list of the last single step (draw_n < 0)
+  int draw_rows[TC_RING_SLOTS][2];
+  int draw_n;
   int step_lds;  // tc_step_kernel: LDS bytes per workgroup (lds.total grown like frame_lds)
+  int seg_lds_limit;  // TC_SEG_LDS_CAP
   int frame_lds, seg_lds_off, seg_lds_cap;  // tc_frame_kernel: LDS bytes per workgroup, draw-list region (see KArgs)
   int frame_streams;  // short K-step calls: frame launches of consecutive chunks alternate between two streams (TC_FRAME_STREAMS)
   int prof_piped[TC_PROF_RING];
   int envg_map_lds; // tc_envg_kernel keeps the edge records in LDS when they fit (TC_ENVG_MAP_LDS=0: always from global)
+  int first_per_env;  // the first chunk of a pipelined call goes through tc_env_kernel (TC_FIRST_CHUNK_PER_ENV=0: grouped too)
   int env_grouped;  // K-step calls: simulate with tc_envg_kernel (TC_EL lanes per env); TC_ENV_GROUPED=0 keeps one wavefront per env
-  int *segm_g, *segm_n;  // [segm_rows][N][seg_cap][5], [segm_rows][N]
-  double* pose_rows;     // [segm_rows][N][TC_POSE_ROW]
-  int segm_rows;
+  // scratch ring of K-step calls (tc_env_reserve_steps): TC_RING_SLOTS chunks of ring_rows steps
+  int *segm_g, *segm_n;  // [TC_RING_SLOTS * ring_rows][N][seg_cap][5], [..][N]
+  double* pose_rows;     // [TC_RING_SLOTS * ring_rows][N][TC_POSE_ROW]
+  int ring_rows;
   int kvar;  // register-cache slots of the simulate stage: 5, 8 (whole map in one window), 9 (camera layer groups), 13
-  hipStream_t side[TC_MAX_SPLIT];
-  hipEvent_t fork_ev, join_ev[TC_MAX_SPLIT];
   // optional per-kernel timing: a ring of (start, mid, end) HIP events recorded on the caller's stream
   int prof;    // 0 = off, n = record every n-th tc_step
   int prof_n;  // launches recorded so far
@@ -2842,7 +2882,6 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   e->prof_n = 0;
   e->prof_calls = 0;
   memset(e->ev, 0, sizeof(e->ev));
-  e->split = 1;
   e->fuse = 1;
   if (const char* fu = getenv("TC_FUSE")) e->fuse = atoi(fu) != 0;
   e->multi_split = 1;
@@ -2852,11 +2891,20 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   e->envg_map_lds = 1;
   if (const char* ml = getenv("TC_ENVG_MAP_LDS")) e->envg_map_lds = atoi(ml) != 0;
   e->chunk = 16;
-  if (const char* ch = getenv("TC_CHUNK")) e->chunk = atoi(ch) > 0 ? atoi(ch) : 0;
-  e->chunk_div = 4;
-  if (const char* cd = getenv("TC_CHUNK_DIV")) e->chunk_div = atoi(cd) > 0 ? atoi(cd) : 4;
+  e->pipe = 1;
+  if (const char* ch = getenv("TC_CHUNK")) {
+    if (atoi(ch) > 0)
+      e->chunk = atoi(ch);
+    else
+      e->pipe = 0;
+  }
   e->frame_stream = e->frame_stream2 = nullptr;
-  e->sim_ev = e->frames_ev = e->frames_ev2 = nullptr;
+  e->sim_ev = e->frames_ev = e->frames_ev2 = e->call_ev = nullptr;
+  memset(e->slot_ev, 0, sizeof(e->slot_ev));
+  e->last_stream = nullptr;
+  e->have_call = false;
+  e->first_per_env = 1;
+  if (const char* fp = getenv("TC_FIRST_CHUNK_PER_ENV")) e->first_per_env = atoi(fp) != 0;
   e->frame_streams = 2;
   if (const char* fsn = getenv("TC_FRAME_STREAMS")) e->frame_streams = atoi(fsn) == 1 ? 1 : 2;
   memset(e->prof_piped, 0, sizeof(e->prof_piped));
@@ -2864,33 +2912,19 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
       hipStreamCreateWithFlags(&e->frame_stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->frames_ev2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->sim_ev, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->frames_ev, hipEventDisableTiming) != hipSuccess) {
-    set_err("tc_env_create: cannot create the internal frame stream");
-    delete e;
+      hipEventCreateWithFlags(&e->frames_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->call_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->slot_ev[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->slot_ev[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->slot_ev[2], hipEventDisableTiming) != hipSuccess) {
+    set_err("tc_env_create: cannot create the internal frame streams / events");
+    tc_env_destroy(e);
     return TC_E_HIP;
   }
+  static_assert(TC_RING_SLOTS == 3, "slot events are created one by one above");
   e->segm_g = e->segm_n = nullptr;
   e->pose_rows = nullptr;
-  e->segm_rows = 0;
-  if (const char* sp = getenv("TC_SPLIT")) {
-    int v = atoi(sp);
-    if (v >= 1 && v <= TC_MAX_SPLIT) e->split = v;
-  }
-  memset(e->side, 0, sizeof(e->side));
-  memset(e->join_ev, 0, sizeof(e->join_ev));
-  e->fork_ev = nullptr;
-  for (int p = 1; p < e->split; p++) {
-    if (hipStreamCreateWithFlags(&e->side[p], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->join_ev[p], hipEventDisableTiming) != hipSuccess) {
-      set_err("tc_env_create: cannot create internal streams");
-      delete e;
-      return TC_E_HIP;
-    }
-  }
-  if (e->split > 1 && hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming) != hipSuccess) {
-    delete e;
-    return TC_E_HIP;
-  }
+  e->ring_rows = 0;
   e->k.m = map->d;
   e->k.N = num_envs;
   DevCar& c = e->k.car;
@@ -3016,11 +3050,19 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
     e->frame_lds = e->step_lds = grown;
     e->seg_lds_off = L.off_live;
     e->seg_lds_cap = (grown - L.off_live) / 20;
+    e->seg_lds_limit = 1 << 30;
     if (const char* sl = getenv("TC_SEG_LDS")) {
       if (atoi(sl) == 0) {
         e->seg_lds_cap = 0;
         e->frame_lds = e->step_lds = L.total;
       }
+    }
+    // TC_SEG_LDS_CAP=n: at most n segments of a frame's draw list stay in LDS (tests: a small n makes every frame take
+    // the mixed LDS + global list that otherwise only frames with more than ~44 segments reach)
+    if (const char* sc = getenv("TC_SEG_LDS_CAP")) {
+      const int v = atoi(sc);
+      if (v >= 0) e->seg_lds_limit = v;
+      if (e->seg_lds_cap > e->seg_lds_limit) e->seg_lds_cap = e->seg_lds_limit;
     }
   }
   if (L.total > 160 * 1024 || e->r_lds > 160 * 1024) {
@@ -3119,11 +3161,9 @@ extern "C" int tc_env_destroy(tc_env* e) {
     for (int k = 0; k < 4; k++)
       for (int i = 0; i < TC_PROF_RING; i++) (void)hipEventDestroy(e->ev[k][i]);
   if (e) {
-    for (int p = 1; p < TC_MAX_SPLIT; p++) {
-      if (e->side[p]) (void)hipStreamDestroy(e->side[p]);
-      if (e->join_ev[p]) (void)hipEventDestroy(e->join_ev[p]);
-    }
-    if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+    for (int sl = 0; sl < TC_RING_SLOTS; sl++)
+      if (e->slot_ev[sl]) (void)hipEventDestroy(e->slot_ev[sl]);
+    if (e->call_ev) (void)hipEventDestroy(e->call_ev);
     if (e->frame_stream) (void)hipStreamDestroy(e->frame_stream);
     if (e->frame_stream2) (void)hipStreamDestroy(e->frame_stream2);
     if (e->frames_ev2) (void)hipEventDestroy(e->frames_ev2);
@@ -3419,9 +3459,9 @@ static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_c
   r.mask = mask;
   r.off_tab = e->r_off_tab;
   r.off_bits = e->r_off_bits;
-  static const bool zero_first = getenv("TC_RGB_ZERO_FIRST") && atoi(getenv("TC_RGB_ZERO_FIRST")) != 0;
-  r.flags = flags | (zero_first ? RF_ZERO_FIRST : 0u);
+  r.flags = flags;
   r.seg_row0 = 0;
+  r.noise_row0 = 0;
   r.obs_row_stride = 0;
   if (with_noise && e->noise_blobs > 0 && c.format == TC_FMT_CLASSES) {
     r.noise_blobs = e->noise_blobs;
@@ -3464,19 +3504,53 @@ static int noise_advance(tc_env* e, int mode, bool rendered, int nsteps, void* s
   return TC_OK;
 }
 
-// steps per simulate / frame dispatch of a K-step call that renders every step (see launch()): TC_CHUNK, or a quarter
-// of the call when that is less; nsteps when the call is not pipelined
+// steps per simulate / frame dispatch of a K-step call that renders (see launch()): TC_CHUNK (16), or a quarter of the
+// call when that is less, so that a short call (the 20 steps of a smoke benchmark) still has several chunks in flight;
+// never more than a ring slot holds.  Calls that are not pipelined run in chunks as large as the ring allows.
 static int chunk_steps(const tc_env* e, int nsteps, bool frames, bool all) {
-  const bool can_pipe = frames && e->env_grouped && e->chunk > 0 && all && nsteps > 1;
-  if (!can_pipe) return nsteps;
-  const int dv = e->chunk_div > 0 ? e->chunk_div : 4;
-  const int q = (nsteps + dv - 1) / dv;
-  return e->chunk < q ? e->chunk : (q < 2 ? 2 : q);
+  const bool can_pipe = frames && e->env_grouped && e->pipe && all && nsteps > 1;
+  int c = nsteps;
+  if (can_pipe) {
+    const int q = (nsteps + 3) / 4;
+    c = e->chunk < q ? e->chunk : (q < 2 ? 2 : q);
+  }
+  if (e->ring_rows > 0 && c > e->ring_rows) c = e->ring_rows;
+  return c;
 }
 
 static bool fused_path(const tc_env* e, uint32_t flags) {
   const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
   return do_raster && e->fuse && e->kvar != 13;
+}
+
+extern "C" int tc_env_reserve_steps(tc_env* e, int32_t max_chunk_steps) {
+  if (!e || max_chunk_steps < 1) return TC_E_INVALID;
+  int rows = max_chunk_steps < e->chunk ? max_chunk_steps : e->chunk;
+  if (rows < 2) rows = 2;  // (a pipelined call never uses chunks of fewer than 2 steps)
+  if (e->ring_rows >= rows) return TC_OK;
+  HIP_TRY(hipDeviceSynchronize());  // earlier launches may still read the old ring
+  if (e->segm_g) (void)hipFree(e->segm_g);
+  if (e->segm_n) (void)hipFree(e->segm_n);
+  if (e->pose_rows) (void)hipFree(e->pose_rows);
+  e->segm_g = e->segm_n = nullptr;
+  e->pose_rows = nullptr;
+  e->ring_rows = 0;
+  const size_t R = (size_t)TC_RING_SLOTS * rows * e->k.N;
+  void *p = nullptr, *q = nullptr, *pr = nullptr;
+  hipError_t he = hipMalloc(&p, R * e->k.seg_cap * 5 * sizeof(int));
+  if (he == hipSuccess) he = hipMalloc(&q, R * sizeof(int));
+  if (he == hipSuccess) he = hipMalloc(&pr, R * TC_POSE_ROW * sizeof(double));
+  if (he != hipSuccess) {
+    if (p) (void)hipFree(p);
+    if (q) (void)hipFree(q);
+    set_err(std::string("hipMalloc(scratch ring of K-step calls): ") + hipGetErrorString(he));
+    return TC_E_NOMEM;
+  }
+  e->segm_g = (int*)p;
+  e->segm_n = (int*)q;
+  e->pose_rows = (double*)pr;
+  e->ring_rows = rows;
+  return TC_OK;
 }
 
 static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t* man, const int32_t* spawn,
@@ -3517,36 +3591,18 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   memset(&ma, 0, sizeof(ma));
   ma.nsteps = nsteps;
   if (roll) ma.roll = *roll;
-  // sub-batches only pay off with an observation to rasterise and enough envs per part; profiled steps stay whole
-  int parts = (do_raster && !prof && N >= 256 * e->split && nsteps == 1) ? e->split : 1;
   hipStream_t main = (hipStream_t)stream;
-  if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], main));
-  if (parts > 1) HIP_TRY(hipEventRecord(e->fork_ev, main));
   if (do_raster && nsteps > 1 && (e->multi_split || !e->fuse || kv == 13)) {
-    // K steps, split form: ONE simulate launch over the steps, ONE launch over the frames wanted
-    if (e->segm_rows < nsteps) {
-      HIP_TRY(hipDeviceSynchronize());  // earlier launches may still read the old buffers
-      if (e->segm_g) (void)hipFree(e->segm_g);
-      if (e->segm_n) (void)hipFree(e->segm_n);
-      if (e->pose_rows) (void)hipFree(e->pose_rows);
-      e->segm_g = e->segm_n = nullptr;
-      e->pose_rows = nullptr;
-      e->segm_rows = 0;
-      void *p = nullptr, *q = nullptr, *pr = nullptr;
-      hipError_t he = hipMalloc(&p, (size_t)nsteps * N * e->k.seg_cap * 5 * sizeof(int));
-      if (he == hipSuccess) he = hipMalloc(&q, (size_t)nsteps * N * sizeof(int));
-      if (he == hipSuccess) he = hipMalloc(&pr, (size_t)nsteps * N * TC_POSE_ROW * sizeof(double));
-      if (he != hipSuccess) {
-        if (p) (void)hipFree(p);
-        if (q) (void)hipFree(q);
-        set_err(std::string("hipMalloc(per-step buffers of a K-step launch): ") + hipGetErrorString(he));
-        return TC_E_NOMEM;
-      }
-      e->segm_g = (int*)p;
-      e->segm_n = (int*)q;
-      e->pose_rows = (double*)pr;
-      e->segm_rows = nsteps;
+    // K steps, split form: per chunk ONE simulate launch over its steps and ONE launch over the frames wanted.  The pose
+    // rows / draw lists of a chunk live in slot (chunk index mod TC_RING_SLOTS) of the scratch ring.
+    if (e->ring_rows < 1) {
+      set_err("tc_step_multi with observations needs the scratch ring: call tc_env_reserve_steps(env, n) once before "
+              "(tc_step_multi itself never allocates)");
+      return TC_E_INVALID;
     }
+    if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], main));
+    // one stream at a time per handle: a call on another stream than the previous K-step call waits for that call
+    if (e->have_call && e->last_stream != main) HIP_TRY(hipStreamWaitEvent(main, e->call_ev, 0));
     const bool frames = e->fuse && kv != 13;  // camera + raster per frame (tc_frame_kernel); else camera in the simulate
                                               // launch (the register-hungry K = 13 stage, TC_FUSE=0) and a raster launch
     // Pipelining inside the call.  The steps are issued in chunks: the simulate launch of chunk c+1 runs on the caller's
@@ -3554,24 +3610,11 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     // on the caller's stream, so the caller still sees everything complete in stream order).  The two kernels suit
     // each other: the frame kernel is bound by vector issue, the grouped simulate kernel by latency (512 wavefronts
     // for 4096 envs), so the second hides in the first's shadow instead of adding its 21 us per step.
+    // (Measured and dropped, DESIGN.md section 4: chunk sizes ramping up 1, 2, 4, ...; a short or half first chunk; other
+    // divisors than 4 for short calls.)
     const bool all = roll && roll->obs;  // with a rollout every step's frame is wanted; else only the last survives
-    // Chunks of TC_CHUNK (16) steps, or a quarter of the call when that is less, so that a short call (the 20 steps of a
-    // smoke benchmark) still has several chunks in flight.  The first simulate launch is the one thing nothing overlaps
-    // with; starting with 1, 2, 4, ... steps to shorten it (TC_RAMP=1) was measured and is slower: frame launches of
-    // one or two steps are too small for the dispatcher to balance (cfg3, 20 / 40 / 100-step calls: 53.2 / 47.9 / 40.1 us
-    // per step with the ramp, 50.3 / 43.7 / 39.5 with equal chunks; 50.9 with no pipelining at all).
-    const bool can_pipe = frames && e->env_grouped && e->chunk > 0 && all && nsteps > 1;
-    static const int ramp = getenv("TC_RAMP") ? atoi(getenv("TC_RAMP")) : 0;
-    int chunk = (can_pipe && ramp == 1) ? 1 : chunk_steps(e, nsteps, frames, all);
-    const int chunk_full = chunk;
-    if (can_pipe && ramp == 2) chunk = chunk / 4 < 2 ? 2 : chunk / 4;  // a short first chunk: less un-overlapped simulate time
-    int chunk_rest = chunk_full;
-    if (can_pipe && ramp == 3 && nsteps > 4) {  // half a chunk first, the rest in equal chunks
-      chunk = (chunk_full + 1) / 2;
-      const int left = nsteps - chunk, nrest = (left + chunk_full - 1) / chunk_full;
-      chunk_rest = (left + nrest - 1) / nrest;
-    }
-    const bool piped = can_pipe;
+    const bool piped = frames && e->env_grouped && e->pipe && all && nsteps > 1;
+    const int chunk = chunk_steps(e, nsteps, frames, all);
     hipStream_t fs = piped ? e->frame_stream : main;
     // Short calls (chunks of fewer than 8 steps): a frame launch of 5 x N workgroups spends a good part of its life
     // ramping up and draining (5 rows: 34.6 us per row alone, 16 rows: 30.8), and a 20-step call is four of them.  There
@@ -3579,35 +3622,51 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     // simulate launch -- so that chunk c+1's workgroups fill the slots chunk c's tail leaves empty (cfg3: 8-step call
     // 66.2 -> 58.3 us per step, 20-step call 46.9 -> 44.0; with chunks of 10 steps it costs 7 %, so longer calls keep one
     // stream and their frame launches follow one another, as a kernel trace of the default command shows them).
-    const bool two_fs = piped && e->frame_streams == 2 && chunk_full < 8;
-    int chunk_no = 0;
+    const bool two_fs = piped && e->frame_streams == 2 && chunk < 8;
     const size_t esz = cdtype == TC_F32 ? 4 : 8;
     const bool thick = e->k.cam.thickness > 1, cls = e->k.cam.format == TC_FMT_CLASSES;
     (void)thick;
     (void)cls;
     bool first_frames = true;
-    for (int c0 = 0, cn = 0; c0 < nsteps;
-         c0 += cn, chunk = !(can_pipe && ramp) ? chunk : ramp == 2 ? chunk_full : ramp == 3 ? chunk_rest : (chunk * 2 <= e->chunk ? chunk * 2 : e->chunk)) {
+    bool used_fs[2] = {false, false};
+    e->draw_n = 0;
+    const int C = e->k.m.C;
+    int ci = 0;
+    for (int c0 = 0, cn = 0; c0 < nsteps; c0 += cn, ci++) {
       cn = nsteps - c0 < chunk ? nsteps - c0 : chunk;
-      const size_t r0 = (size_t)c0 * N;  // first [step][env] row of this chunk
+      const size_t r0 = (size_t)c0 * N;                 // first [step][env] row of this chunk in the caller's arrays
+      const int rslot = ci % TC_RING_SLOTS;
+      const size_t rb = (size_t)rslot * e->ring_rows;   // first row of this chunk in the scratch ring
+      // the frames that read this ring slot TC_RING_SLOTS chunks ago must be done before it is rewritten
+      if (piped && ci >= TC_RING_SLOTS) HIP_TRY(hipStreamWaitEvent(main, e->slot_ev[rslot], 0));
       StepArgs sa;
       memset(&sa, 0, sizeof(sa));
       sa.a = e->k;
       sa.a.env0 = 0;
-      sa.a.seg_g = e->segm_g + r0 * e->k.seg_cap * 5;
-      sa.a.seg_n = e->segm_n + r0;
+      sa.a.seg_g = e->segm_g + rb * N * e->k.seg_cap * 5;
+      sa.a.seg_n = e->segm_n + rb * N;
       sa.ma = ma;
       sa.ma.nsteps = cn;
       sa.ma.seg_rows = cn > 1 ? cn : 2;  // (> 1: row k of the chunk's lists; a one-step chunk still writes row 0 of them)
       sa.ma.cam_here = frames ? 0 : 1;
-      sa.ma.pose_rows = frames ? e->pose_rows + r0 * TC_POSE_ROW : nullptr;
+      sa.ma.pose_rows = frames ? e->pose_rows + rb * N * TC_POSE_ROW : nullptr;
       if (roll) {
-        sa.ma.roll.obs = roll->obs ? roll->obs + r0 * (size_t)e->obs_bytes : nullptr;
-        sa.ma.roll.reward = roll->reward ? roll->reward + r0 : nullptr;
-        sa.ma.roll.terminated = roll->terminated ? roll->terminated + r0 : nullptr;
-        sa.ma.roll.truncated = roll->truncated ? roll->truncated + r0 : nullptr;
-        sa.ma.roll.cte = roll->cte ? roll->cte + r0 : nullptr;
-        sa.ma.roll.heading_error = roll->heading_error ? roll->heading_error + r0 : nullptr;
+        tc_rollout& q = sa.ma.roll;
+        q.obs = roll->obs ? roll->obs + r0 * (size_t)e->obs_bytes : nullptr;
+        q.reward = roll->reward ? roll->reward + r0 : nullptr;
+        q.terminated = roll->terminated ? roll->terminated + r0 : nullptr;
+        q.truncated = roll->truncated ? roll->truncated + r0 : nullptr;
+        q.cte = roll->cte ? roll->cte + r0 : nullptr;
+        q.heading_error = roll->heading_error ? roll->heading_error + r0 : nullptr;
+        q.status = roll->status ? roll->status + r0 : nullptr;
+        q.x = roll->x ? roll->x + r0 : nullptr;
+        q.y = roll->y ? roll->y + r0 : nullptr;
+        q.theta = roll->theta ? roll->theta + r0 : nullptr;
+        q.velocity = roll->velocity ? roll->velocity + r0 : nullptr;
+        q.laneline_distances = roll->laneline_distances ? roll->laneline_distances + r0 * C : nullptr;
+        q.nearest_edge = roll->nearest_edge ? roll->nearest_edge + r0 * C : nullptr;
+        q.local_path = roll->local_path ? roll->local_path + r0 * 8 : nullptr;
+        q.lp_len = roll->lp_len ? roll->lp_len + r0 : nullptr;
       }
       sa.mode = mode;
       sa.cdtype = cdtype;
@@ -3620,8 +3679,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       // the one-wavefront-per-env kernel (4096 wavefronts, bound by throughput: ~15 us per step) instead of the grouped
       // one (512 wavefronts, a latency chain: 13-23 us per step).  20-step call 48.4 -> 47.2 us per step, 128-step calls
       // 38.2 -> 37.6.  Both kernels read and leave the env's state in the caller's buffers, bit for bit the same.
-      static const bool first_per_env = getenv("TC_FIRST_CHUNK_PER_ENV") ? atoi(getenv("TC_FIRST_CHUNK_PER_ENV")) != 0 : true;
-      if (frames && e->env_grouped && !(first_per_env && c0 == 0 && piped && nsteps > chunk)) {  // (a one-chunk call: grouped)
+      if (frames && e->env_grouped && !(e->first_per_env && c0 == 0 && piped && nsteps > chunk)) {  // (a one-chunk call: grouped)
         const size_t map_bytes = (size_t)e->k.m.total_edges * 48;
         sa.ma.map_lds = (e->envg_map_lds && map_bytes <= 40 * 1024) ? 1 : 0;
         hipLaunchKernelGGL(tc_envg_kernel, dim3((N + TC_ENVG_NT / TC_EL - 1) / (TC_ENVG_NT / TC_EL)), dim3(TC_ENVG_NT),
@@ -3633,73 +3691,77 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       const bool last_chunk = c0 + cn >= nsteps;
       if (prof && last_chunk) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
       if (!all && !last_chunk) continue;  // only the last step's frame is wanted
-      if (two_fs) fs = (chunk_no++ & 1) ? e->frame_stream2 : e->frame_stream;
+      if (two_fs) fs = (ci & 1) ? e->frame_stream2 : e->frame_stream;
       if (piped) {
         HIP_TRY(hipEventRecord(e->sim_ev, main));
         HIP_TRY(hipStreamWaitEvent(fs, e->sim_ev, 0));
+        used_fs[fs == e->frame_stream2 ? 1 : 0] = true;
       }
       if (prof && first_frames && piped) HIP_TRY(hipEventRecord(e->ev[3][slot], fs));
       first_frames = false;
       RArgs r = make_rargs(e, e->segm_g, e->segm_n, e->k.seg_cap, nullptr, flags, 0, all ? roll->obs + r0 * (size_t)e->obs_bytes : nullptr,
                            mode == MODE_STEP);
-      r.seg_row0 = all ? c0 : nsteps - 1;  // absolute step index of the call: draw-list / pose row and blob stream position
+      // scratch row of the first frame drawn / its step index in the call (position in the blob stream)
+      r.seg_row0 = (int)rb + (all ? 0 : cn - 1);
+      r.noise_row0 = all ? c0 : nsteps - 1;
       r.obs_row_stride = all ? (long long)N * (long long)e->obs_bytes : 0;
-      const int rows = all ? cn : 1;
-      for (int row0 = 0; row0 < rows; row0 += 65535) {  // grid.y limit
-        RArgs rr = r;
-        rr.seg_row0 = r.seg_row0 + row0;
-        rr.obs += (size_t)row0 * (size_t)r.obs_row_stride;
-        const int ny = rows - row0 < 65535 ? rows - row0 : 65535;
-        if (frames) {
-          FrameArgs fa;
-          memset(&fa, 0, sizeof(fa));
-          fa.a = e->k;
-          fa.a.dbg = flags;
-          fa.a.env0 = 0;
-          fa.a.seg_g = e->segm_g;
-          fa.a.seg_n = e->segm_n;
-          fa.r = rr;
-          fa.pose_rows = e->pose_rows;
-          frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
-          fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
-          fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->seg_lds_cap;
-          hipLaunchKernelGGL(fk, dim3(N, ny), dim3(TC_NT), e->frame_lds, fs, fa);
-        } else {
+      const int rows = all ? cn : 1;  // (<= ring_rows <= 16: one grid)
+      if (frames) {
+        FrameArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.a = e->k;
+        fa.a.dbg = flags;
+        fa.a.env0 = 0;
+        fa.a.seg_g = e->segm_g;
+        fa.a.seg_n = e->segm_n;
+        fa.r = r;
+        fa.pose_rows = e->pose_rows;
+        frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
+        fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
+        fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->seg_lds_cap;
+        hipLaunchKernelGGL(fk, dim3(N, rows), dim3(TC_NT), e->frame_lds, fs, fa);
+      } else {
 #ifdef TC_DEV_FAST
-          auto rk = tc_raster_kernel<true, TC_FMT_CLASSES>;
+        auto rk = tc_raster_kernel<true, TC_FMT_CLASSES>;
 #else
-          auto rk = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
-                          : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
+        auto rk = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
+                        : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
 #endif
-          hipLaunchKernelGGL(rk, dim3(N, ny), dim3(TC_NT), e->r_lds, fs, rr);
-        }
-        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(rk, dim3(N, rows), dim3(TC_NT), e->r_lds, fs, r);
+      }
+      HIP_TRY(hipGetLastError());
+      if (piped) HIP_TRY(hipEventRecord(e->slot_ev[rslot], fs));
+      {  // (the ring keeps the last TC_RING_SLOTS chunks: remember where their draw-list lengths are)
+        const int w = e->draw_n < TC_RING_SLOTS ? e->draw_n++ : (memmove(e->draw_rows[0], e->draw_rows[1], sizeof(int) * 2 * (TC_RING_SLOTS - 1)), TC_RING_SLOTS - 1);
+        e->draw_rows[w][0] = r.seg_row0;
+        e->draw_rows[w][1] = rows;
       }
     }
-    if (two_fs) {  // join both frame streams; the end-of-frames probe then sits on the caller's stream behind the join
-      HIP_TRY(hipEventRecord(e->frames_ev, e->frame_stream));
-      HIP_TRY(hipEventRecord(e->frames_ev2, e->frame_stream2));
-      HIP_TRY(hipStreamWaitEvent(main, e->frames_ev, 0));
-      HIP_TRY(hipStreamWaitEvent(main, e->frames_ev2, 0));
-      if (prof) {
-        HIP_TRY(hipEventRecord(e->ev[2][slot], main));
-        e->prof_piped[slot] = 1;
-        e->prof_n++;
+    // join the frame stream(s) back; the end-of-frames probe then sits on the caller's stream behind the join
+    if (piped) {
+      if (used_fs[0]) {
+        HIP_TRY(hipEventRecord(e->frames_ev, e->frame_stream));
+        HIP_TRY(hipStreamWaitEvent(main, e->frames_ev, 0));
       }
-      return noise_advance(e, mode, true, nsteps, stream);
+      if (used_fs[1]) {
+        HIP_TRY(hipEventRecord(e->frames_ev2, e->frame_stream2));
+        HIP_TRY(hipStreamWaitEvent(main, e->frames_ev2, 0));
+      }
     }
     if (prof) {
-      HIP_TRY(hipEventRecord(e->ev[2][slot], fs));
+      HIP_TRY(hipEventRecord(e->ev[2][slot], main));
       e->prof_piped[slot] = piped ? 1 : 0;
       e->prof_n++;
     }
-    if (piped) {
-      HIP_TRY(hipEventRecord(e->frames_ev, fs));
-      HIP_TRY(hipStreamWaitEvent(main, e->frames_ev, 0));
-    }
-    return noise_advance(e, mode, true, nsteps, stream);
+    int rc = noise_advance(e, mode, true, nsteps, stream);
+    if (rc != TC_OK) return rc;
+    HIP_TRY(hipEventRecord(e->call_ev, main));
+    e->last_stream = main;
+    e->have_call = true;
+    return TC_OK;
   }
-  if (do_raster && e->fuse && parts == 1 && kv != 13) {  // one launch: simulate + raster by the same wavefront
+  if (prof) HIP_TRY(hipEventRecord(e->ev[0][slot], main));
+  if (do_raster && e->fuse && kv != 13) {  // one launch: simulate + raster by the same wavefront
     // (the register-hungry K = 13 simulate stage spills when fused, so it stays two launches)
     const bool thick = e->k.cam.thickness > 1, cls = e->k.cam.format == TC_FMT_CLASSES;
     fused_kern_t fk = kv == 5 ? pick_fused<5>(thick, cls) : kv == 8 ? pick_fused<8>(thick, cls) : pick_fused<9>(thick, cls);
@@ -3711,6 +3773,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     const int lds = e->step_lds;
     k.seg_lds_off = r.seg_lds_off = e->k.lds.total;
     k.seg_lds_cap = r.seg_lds_cap = e->seg_lds_cap ? (e->step_lds - e->k.lds.total) / 20 : 0;
+    if (k.seg_lds_cap > e->seg_lds_limit) k.seg_lds_cap = r.seg_lds_cap = e->seg_lds_limit;
     StepArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.a = k;
@@ -3725,6 +3788,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     sa.mask = mask;
     hipLaunchKernelGGL(fk, dim3(N), dim3(TC_NT), lds, main, sa);
     HIP_TRY(hipGetLastError());
+    e->draw_n = -1;
     if (prof) {  // one kernel: its whole duration is reported as the first interval, the second is empty
       HIP_TRY(hipEventRecord(e->ev[1][slot], main));
       HIP_TRY(hipEventRecord(e->ev[2][slot], main));
@@ -3732,12 +3796,9 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     }
     return noise_advance(e, mode, true, nsteps, stream);
   }
-  for (int p = 0; p < parts; p++) {
-    const int env0 = (int)((long long)N * p / parts), env1 = (int)((long long)N * (p + 1) / parts);
-    hipStream_t st = p == 0 ? main : e->side[p];
-    if (p > 0) HIP_TRY(hipStreamWaitEvent(st, e->fork_ev, 0));
+  {
     KArgs k = e->k;
-    k.env0 = env0;
+    k.env0 = 0;
     StepArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.a = k;
@@ -3752,17 +3813,16 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     sa.mask = mask;
     // (K steps without observations run on the one-wavefront-per-env kernel: with nothing to share the chip with, its
     // shorter serial chain wins -- cfg2: 16.5 us per step against 20.7 for the grouped kernel)
-    hipLaunchKernelGGL(do_raster ? kern : kern_nocam, dim3(env1 - env0), dim3(TC_NT), k.lds.total, st, sa);
+    hipLaunchKernelGGL(do_raster ? kern : kern_nocam, dim3(N), dim3(TC_NT), k.lds.total, main, sa);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
     if (do_raster) {
-      int rc = launch_raster(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, mode == MODE_RESET ? mask : nullptr, flags, st, env0,
-                             env1 - env0, roll ? roll->obs : nullptr, mode == MODE_STEP);
+      int rc = launch_raster(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, mode == MODE_RESET ? mask : nullptr, flags, main, 0, N,
+                             roll ? roll->obs : nullptr, mode == MODE_STEP);
       if (rc != TC_OK) return rc;
+      e->draw_n = -1;
     }
-    if (p > 0) HIP_TRY(hipEventRecord(e->join_ev[p], st));
   }
-  for (int p = 1; p < parts; p++) HIP_TRY(hipStreamWaitEvent(main, e->join_ev[p], 0));
   if (prof) {
     HIP_TRY(hipEventRecord(e->ev[2][slot], main));
     e->prof_n++;
@@ -3793,11 +3853,53 @@ extern "C" int tc_step_multi(tc_env* e, const void* car_control, int32_t control
   return launch(e, MODE_STEP, car_control, control_dtype, maneuver, nullptr, nullptr, flags, stream, n_steps, rollout);
 }
 
+// Workload descriptor for benchmark lines: what the most recent frames actually drew.  Waits for the device and copies
+// the draw-list lengths (one int per frame) to the host: of the last single step's N frames, or of the frames of the
+// last (up to TC_RING_SLOTS) chunks of the last K-step call.
+extern "C" int tc_env_draw_list_stats(tc_env* e, double* mean_segments, double* empty_frac, int32_t* max_segments,
+                                      int64_t* frames) {
+  if (!e || !mean_segments || !empty_frac || !max_segments || !frames) return TC_E_INVALID;
+  *mean_segments = *empty_frac = 0;
+  *max_segments = 0;
+  *frames = 0;
+  if (e->draw_n == 0) return TC_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  const int N = e->k.N;
+  std::vector<int> h;
+  long long tot = 0, empty = 0, cnt = 0;
+  int mx = 0;
+  auto take = [&](const int* dev, size_t n) -> int {
+    h.resize(n);
+    HIP_TRY(hipMemcpy(h.data(), dev, n * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+      tot += h[i];
+      empty += h[i] == 0;
+      mx = h[i] > mx ? h[i] : mx;
+    }
+    cnt += (long long)n;
+    return TC_OK;
+  };
+  if (e->draw_n < 0) {
+    int rc = take(e->k.seg_n, (size_t)N);
+    if (rc != TC_OK) return rc;
+  } else {
+    for (int i = 0; i < e->draw_n; i++) {
+      int rc = take(e->segm_n + (size_t)e->draw_rows[i][0] * N, (size_t)e->draw_rows[i][1] * N);
+      if (rc != TC_OK) return rc;
+    }
+  }
+  *frames = cnt;
+  *mean_segments = cnt ? (double)tot / (double)cnt : 0.0;
+  *empty_frac = cnt ? (double)empty / (double)cnt : 0.0;
+  *max_segments = mx;
+  return TC_OK;
+}
+
 extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar,
                                   int32_t* steps_per_dispatch, char* name, int32_t name_cap) {
   if (!e) return TC_E_INVALID;
   const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
-  const bool f = fused_path(e, flags) && e->split == 1 && !(n_steps > 1 && e->multi_split);
+  const bool f = fused_path(e, flags) && !(n_steps > 1 && e->multi_split);
   if (fused) *fused = f ? 1 : 0;
   if (kvar) *kvar = e->kvar;
   const bool frames = n_steps > 1 && do_raster && !f && e->fuse && e->kvar != 13;

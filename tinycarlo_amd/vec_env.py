@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from collections.abc import Mapping
+import time
 from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -26,6 +26,7 @@ import torch
 
 from . import _native as nat
 from . import gym
+from .config import getenv as gym_getenv
 from .camera import Camera
 from .config import CarParams, load_config
 from .map import Map
@@ -50,46 +51,52 @@ class CarView:
         self.max_deceleration = p.max_deceleration
 
 
-class LazyInfo(Mapping):
-    """info of a batched step (env.py:83-85): same keys as the reference's dict, derived entries built on access."""
+class LazyInfo(dict):
+    """info of a batched step (env.py:83-85): a ``dict`` with the reference's keys.
 
+    The entries the engine writes itself -- ``cte``, ``heading_error``, ``orientation``, ``status`` and the per-layer
+    ``laneline_distances`` -- are views of the env's buffers and are in the dict from the start (no device work).
+    ``position``, ``local_path``, ``local_path_len`` and ``velocity`` each cost a few small torch kernels and are built
+    on first access (``__missing__``); they are listed by ``keys()`` / iteration / ``in`` like the others.  Being a
+    real dict it passes gymnasium's ``isinstance(info, dict)`` check and wrappers may add entries.
+
+    Like every tensor the env hands out, the entries show the env's live buffers.  A derived entry that is first read
+    AFTER the env has stepped again would silently describe the later step, so that raises instead; ``materialize()``
+    returns an independent snapshot (plain dict of clones) for callers that keep infos across steps."""
+
+    DERIVED = ("position", "local_path", "local_path_len", "velocity")
     KEYS = ("cte", "heading_error", "position", "orientation", "laneline_distances", "local_path", "local_path_len",
             "velocity", "status")
 
     def __init__(self, env):
+        st, o = env.state, env.out
+        super().__init__(cte=o["cte"], heading_error=o["heading_error"], orientation=st["theta"], status=o["status"],
+                         laneline_distances={name: o["laneline_distances"][:, i] for i, name in enumerate(env.layer_names)})
         self._env = env
-        self._cache: Dict[str, Any] = {}
+        self._serial = env._step_serial
+        self._valid = None
 
-    def __iter__(self):
-        return iter(self.KEYS)
-
-    def __len__(self):
-        return len(self.KEYS)
-
+    # ---- derived entries
     def _valid_n(self):
         # car.get_info returned real values (car.py:47-51): the local path has its look-ahead edges.  A freshly
         # (re)spawned env has lp_len == 1, and so has one whose tracking stopped early (truncated).  (Not read off
         # nearest_edge[:, 0]: a first lane-line layer without edges would report -1 there for ever.)
-        if "_valid" not in self._cache:
+        if self._valid is None:
             lp_len = self._env.state["lp_len"]
             valid = lp_len >= 2
-            self._cache["_valid"] = valid
-            self._cache["local_path_len"] = torch.where(valid, lp_len, torch.zeros_like(lp_len))
-        return self._cache["_valid"], self._cache["local_path_len"]
+            self._valid = (valid, torch.where(valid, lp_len, torch.zeros_like(lp_len)))
+        return self._valid
 
-    def __getitem__(self, key):
-        if key in self._cache:
-            return self._cache[key]
+    def __missing__(self, key):
+        if key not in self.DERIVED:
+            raise KeyError(key)
         e = self._env
-        st, o = e.state, e.out
-        if key in ("cte", "heading_error", "status"):
-            v = o[key]
-        elif key == "orientation":
-            v = st["theta"]
-        elif key == "position":
+        if e._step_serial != self._serial:
+            raise RuntimeError(f"info[{key!r}] read after the env stepped again: derived entries are built from the env's "
+                               "live buffers; read them before the next step or keep info.materialize()")
+        st = e.state
+        if key == "position":
             v = torch.stack([st["x"], st["y"]], dim=1)
-        elif key == "laneline_distances":
-            v = {name: o["laneline_distances"][:, i] for i, name in enumerate(e.layer_names)}
         elif key == "local_path_len":
             v = self._valid_n()[1]
         elif key == "local_path":
@@ -98,13 +105,42 @@ class LazyInfo(Mapping):
             coords = e._lp_nodes[idx]                              # nodes[edge[1]] per edge (car.py:66)
             keep = (torch.arange(4, device=coords.device)[None, :] < n[:, None])
             v = coords * keep[:, :, None]
-        elif key == "velocity":
+        else:  # velocity
             valid, _ = self._valid_n()
             v = torch.where(valid, st["velocity"], torch.zeros_like(st["velocity"]))
-        else:
-            raise KeyError(key)
-        self._cache[key] = v
+        dict.__setitem__(self, key, v)
         return v
+
+    # ---- the derived keys exist as far as any dict protocol can tell
+    def _all_keys(self):
+        return list(dict.keys(self)) + [k for k in self.DERIVED if not dict.__contains__(self, k)]
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self.DERIVED
+
+    def __iter__(self):
+        return iter(self._all_keys())
+
+    def __len__(self):
+        return len(self._all_keys())
+
+    def keys(self):
+        return self._all_keys()
+
+    def values(self):
+        return [self[k] for k in self._all_keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self._all_keys()]
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def materialize(self) -> Dict[str, Any]:
+        """An independent snapshot: plain dict, every tensor cloned."""
+        def cl(v):
+            return {k: cl(x) for k, x in v.items()} if isinstance(v, dict) else (v.clone() if isinstance(v, torch.Tensor) else v)
+        return {k: cl(self[k]) for k in self._all_keys()}
 
 
 class TinyCarloVecEnv(gym.Env):
@@ -169,6 +205,8 @@ class TinyCarloVecEnv(gym.Env):
         self.track_fresh = False
         self.noise = (0, 0, 0)  # (n_blobs, max_radius, seed) of set_noise
         self.last_fresh: Optional[torch.Tensor] = None
+        self._step_serial = 0      # bumped by every reset / step launch: stale-info detection (LazyInfo)
+        self._reserved_steps = 0   # tc_env_reserve_steps: scratch ring of K-step calls that render
 
     def _setup_device(self) -> None:
         """Creates the native handles and the device tensors the HIP library works on (no CPU path)."""
@@ -421,6 +459,7 @@ class TinyCarloVecEnv(gym.Env):
                                          self._flags() & ~nat.F_AUTORESET, self._stream()), "tc_reset")
         self._keep = (nd, mk)
         self._was_reset = True
+        self._step_serial += 1
 
     def step(self, action: Dict[str, Any]):
         """env.py:115-147 for every env.  action = {"car_control": [N,2] float32|float64, "maneuver": [N] int}."""
@@ -432,7 +471,13 @@ class TinyCarloVecEnv(gym.Env):
             dt = torch.float32 if cc.dtype == np.float32 else torch.float64
         cc_t = self._to_dev("car_control", cc, dt, (self.num_envs, 2))
         mn_t = self._to_dev("maneuver", action["maneuver"], torch.int32, (self.num_envs,))
+        dbg = gym_getenv("DEBUG")  # env.py:144 reads the switch on every step
+        if dbg:
+            t_dbg = time.perf_counter()
+            self.profile(1)
         self.step_device(cc_t, mn_t)
+        if dbg:
+            self._debug_print("step", t_dbg)
         o = self.out
         if self.return_numpy:
             return (self._obs(), o["reward"].cpu().numpy(), o["terminated"].cpu().numpy().astype(bool),
@@ -450,19 +495,68 @@ class TinyCarloVecEnv(gym.Env):
             nat.check(nat.lib().tc_step(self._h, car_control.data_ptr(), dt, maneuver.data_ptr(), self._flags(),
                                         self._stream()), "tc_step")
         self._keep = (car_control, maneuver)
+        self._step_serial += 1
+
+    def _debug_print(self, what: str, t0: float) -> None:
+        """DEBUG=1 (helper.py:4-9; env.py:116-129,144-145 prints `all | obs render | info | car step` from
+        time.perf_counter): here the phases are kernels, timed with HIP events on the launch stream (tc_env_profile):
+        `simulate` = car.step + get_info (+ camera and raster when the step is one fused kernel), `frames` = camera +
+        raster when they run as launches of their own.  Waits for the launch, like the reference's timer does."""
+        p = self.profile_read()
+        self.profile(0)
+        all_ms = (time.perf_counter() - t0) * 1000
+        print(f"{what}: all: {all_ms:.2f} ms | kernels: simulate {p['simulate_us'] / 1000:.4f} ms | frames "
+              f"{p['raster_us'] / 1000:.4f} ms | {self.num_envs} envs")
 
     ROLLOUT_KEYS = ("obs", "reward", "terminated", "truncated", "cte", "heading_error")
+    # the rest of step()'s info dict (env.py:83-85) and the status bits, per step (ABI 5)
+    INFO_ROLLOUT_KEYS = ("status", "x", "y", "theta", "velocity", "laneline_distances", "nearest_edge", "local_path", "lp_len")
+
+    def _rollout_shapes(self, K: int):
+        N, Cn = self.num_envs, self.n_classes
+        f64, i32, u8 = torch.float64, torch.int32, torch.uint8
+        return {"obs": ((K, N) + self._obs_shape, u8), "reward": ((K, N), f64), "terminated": ((K, N), u8),
+                "truncated": ((K, N), u8), "cte": ((K, N), f64), "heading_error": ((K, N), f64),
+                "status": ((K, N), i32), "x": ((K, N), f64), "y": ((K, N), f64), "theta": ((K, N), f64),
+                "velocity": ((K, N), f64), "laneline_distances": ((K, N, Cn), f64), "nearest_edge": ((K, N, Cn), i32),
+                "local_path": ((K, N, 8), i32), "lp_len": ((K, N), i32)}
+
+    def reserve_steps(self, n_steps: int) -> None:
+        """Sizes the library's scratch ring for K-step calls that render observations (tc_env_reserve_steps): done
+        once, outside any timed or captured region -- `step_multi` itself never allocates.  `step_multi` calls this on
+        first use; call it yourself before capturing a `step_multi` into a HIP graph."""
+        if int(n_steps) > self._reserved_steps:
+            with torch.cuda.device(self.device):
+                nat.check(nat.lib().tc_env_reserve_steps(self._h, int(n_steps)), "tc_env_reserve_steps")
+            self._reserved_steps = int(n_steps)
 
     def alloc_rollout(self, n_steps: int, keys: Sequence[str] = ("obs", "reward", "terminated", "truncated")) -> Dict[str, torch.Tensor]:
         """Device tensors for the per-step outputs of `step_multi`: [n_steps, num_envs, ...] each."""
-        K, N, dev = int(n_steps), self.num_envs, self.device
-        shapes = {"obs": ((K, N) + self._obs_shape, torch.uint8), "reward": ((K, N), torch.float64),
-                  "terminated": ((K, N), torch.uint8), "truncated": ((K, N), torch.uint8),
-                  "cte": ((K, N), torch.float64), "heading_error": ((K, N), torch.float64)}
+        K, dev = int(n_steps), self.device
+        shapes = self._rollout_shapes(K)
+        if keys == "all":
+            keys = self.ROLLOUT_KEYS + self.INFO_ROLLOUT_KEYS
         for k in keys:
             if k not in shapes:
-                raise ValueError(f"unknown rollout key {k!r}; choose from {self.ROLLOUT_KEYS}")
+                raise ValueError(f"unknown rollout key {k!r}; choose from {self.ROLLOUT_KEYS + self.INFO_ROLLOUT_KEYS}")
         return {k: torch.zeros(shapes[k][0], dtype=shapes[k][1], device=dev) for k in keys}
+
+    def rollout_info(self, rollout: Dict[str, torch.Tensor], k: int) -> Dict[str, Any]:
+        """info dict of step k of a `step_multi` call (env.py:83-85 per step), built from the rollout's info rows
+        (`alloc_rollout(K, keys="all")` or at least INFO_ROLLOUT_KEYS + cte + heading_error): same keys and values as
+        `step()`'s info after the k-th of K single steps."""
+        lp_len = rollout["lp_len"][k]
+        valid = lp_len >= 2
+        n = torch.where(valid, lp_len, torch.zeros_like(lp_len))
+        idx = rollout["local_path"][k][:, 1::2].long().clamp(min=0)
+        coords = self._lp_nodes[idx]
+        keep = (torch.arange(4, device=coords.device)[None, :] < n[:, None])
+        vel = rollout["velocity"][k]
+        return {"cte": rollout["cte"][k], "heading_error": rollout["heading_error"][k],
+                "position": torch.stack([rollout["x"][k], rollout["y"][k]], dim=1), "orientation": rollout["theta"][k],
+                "laneline_distances": {name: rollout["laneline_distances"][k][:, i] for i, name in enumerate(self.layer_names)},
+                "local_path": coords * keep[:, :, None], "local_path_len": n,
+                "velocity": torch.where(valid, vel, torch.zeros_like(vel)), "status": rollout["status"][k]}
 
     def step_multi(self, car_control: torch.Tensor, maneuver: torch.Tensor,
                    rollout: Optional[Dict[str, torch.Tensor]] = None) -> None:
@@ -485,25 +579,30 @@ class TinyCarloVecEnv(gym.Env):
         if not (car_control.is_contiguous() and maneuver.is_contiguous()):
             raise ValueError("step_multi takes contiguous tensors")
         self._note_fresh()
+        dbg = gym_getenv("DEBUG")
+        if dbg:
+            t_dbg = time.perf_counter()
+            self.profile(1)
         r = nat.Rollout()
         if rollout:
-            want = {"obs": (torch.uint8, (K, self.num_envs) + self._obs_shape)}
-            for k in ("reward", "cte", "heading_error"):
-                want[k] = (torch.float64, (K, self.num_envs))
-            for k in ("terminated", "truncated"):
-                want[k] = (torch.uint8, (K, self.num_envs))
+            want = self._rollout_shapes(K)
             for k, t in rollout.items():
                 if k not in want:
                     raise ValueError(f"unknown rollout key {k!r}")
-                dt_, shp = want[k]
+                shp, dt_ = want[k]
                 if t.dtype != dt_ or tuple(t.shape) != shp or t.device != self.device or not t.is_contiguous():
                     raise ValueError(f"rollout[{k!r}] must be a contiguous {dt_} tensor of shape {shp} on {self.device}")
                 setattr(r, k, t.data_ptr())
         dt = nat.F64 if car_control.dtype == torch.float64 else nat.F32
+        if K > 1 and not (self.no_observation and self.render_mode is None):
+            self.reserve_steps(K)  # (no-op once the ring covers K: the call below never allocates)
         with torch.cuda.device(self.device):
             nat.check(nat.lib().tc_step_multi(self._h, car_control.data_ptr(), dt, maneuver.data_ptr(), K, self._flags(),
                                               C.byref(r) if rollout else None, self._stream()), "tc_step_multi")
         self._keep = (car_control, maneuver, rollout)
+        self._step_serial += 1
+        if dbg:
+            self._debug_print(f"step_multi[{K}]", t_dbg)
 
     def launch_info(self, n_steps: int = 1) -> Dict[str, Any]:
         """What a call of n_steps steps launches with the current settings (tc_env_launch_info): for benchmark labels."""
@@ -511,6 +610,14 @@ class TinyCarloVecEnv(gym.Env):
         nat.check(nat.lib().tc_env_launch_info(self._h, self._flags(), int(n_steps), C.byref(f), C.byref(kv), C.byref(spd),
                                                name, 64), "tc_env_launch_info")
         return {"fused": bool(f.value), "kvar": kv.value, "kernel": name.value.decode(), "steps_per_dispatch": spd.value}
+
+    def draw_list_stats(self) -> Dict[str, Any]:
+        """What the most recent frames drew (tc_env_draw_list_stats; waits for the device): workload descriptor."""
+        m, e, mx, fr = C.c_double(), C.c_double(), C.c_int32(), C.c_int64()
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().tc_env_draw_list_stats(self._h, C.byref(m), C.byref(e), C.byref(mx), C.byref(fr)),
+                      "tc_env_draw_list_stats")
+        return {"mean_segments_per_frame": m.value, "empty_frame_frac": e.value, "max_segments": mx.value, "frames": fr.value}
 
     def request_reset(self, mask: torch.Tensor) -> None:
         """Marks envs for re-spawning at the start of the next autoreset step, in addition to the ones the engine
@@ -584,7 +691,8 @@ class TinyCarloVecEnv(gym.Env):
         `local_path_len` and `velocity` (0 while the info is empty, car.py:47-51) each cost a few small torch kernels,
         so they are built when read: a training loop that only looks at the observation and the reward does not pay
         for them on every step (step() was 147 us against 85 us for the bare launch in round 1).  Like every tensor
-        the env hands out they show the env's buffers: read them before the next step (or clone them).
+        the env hands out they show the env's buffers: read them before the next step (a derived entry first read
+        after the next step raises) or keep `info.materialize()`.
         With return_numpy=True everything is materialised at once as host arrays."""
         info = LazyInfo(self)
         if self.return_numpy:
