@@ -272,38 +272,47 @@ def main():
         age = torch.where(last >= 0, (k - 1 - last).to(torch.int64), age + k)
         pend = done[-1].clone()
 
-    def issue(t0, cnt, sink=None, m=None):
-        """steps t0 .. t0+cnt-1 of the action stream, m per launch (default: M); returns the number of launches"""
+    def plan(t0, cnt, m=None):
+        """The calls that cover steps t0 .. t0+cnt-1 of the action stream, m steps per call (default: M), with their
+        argument tensors already sliced: the timed region then contains the calls and nothing else (one 20-step call is
+        0.9 ms of GPU time; slicing its tensors inside the bracket would be several per cent of it)."""
         m = M if m is None else m
-        nl = 0
         if m == 0:
-            for t in range(t0, t0 + cnt):
-                i = t % period
-                env.step_device(cc[i], man[i])
-            return cnt
-        # cnt steps as ceil(cnt / m) launches of (almost) equal size: no short last launch skews the per-launch means
+            return [(cc[t % period], man[t % period], None) for t in range(t0, t0 + cnt)]
+        # cnt steps as ceil(cnt / m) calls of (almost) equal size: no short last call skews the per-call means
         n_launch = -(-cnt // m)
         base, rem = divmod(cnt, n_launch)
-        t = t0
+        out, t = [], t0
         for j in range(n_launch):
             want = base + (1 if j < rem else 0)
-            while want > 0:  # (a launch is only split where the cyclic action buffer wraps around)
+            while want > 0:  # (a call is only split where the cyclic action buffer wraps around)
                 i = t % period
                 kk = min(want, period - i)
-                if sink is not None:
-                    sink.launch(cc[i:i + kk], man[i:i + kk])
-                else:
-                    r = None if roll is None else (roll if kk == M else {k_: v[:kk] for k_, v in roll.items()})
-                    if r is not None and flag_rows is not None:  # timed region: flag rows of every step are kept
-                        f0 = t - flag_rows["t0"]
-                        r = dict(r, terminated=flag_rows["terminated"][f0:f0 + kk], truncated=flag_rows["truncated"][f0:f0 + kk])
-                    env.step_multi(cc[i:i + kk], man[i:i + kk], rollout=r)
-                    if r is not None and flag_rows is None:
-                        fold_flags(r["terminated"], r["truncated"])
+                r = None if roll is None else (roll if kk == M else {k_: v[:kk] for k_, v in roll.items()})
+                if r is not None and flag_rows is not None:  # timed region: flag rows of every step are kept
+                    f0 = t - flag_rows["t0"]
+                    r = dict(r, terminated=flag_rows["terminated"][f0:f0 + kk], truncated=flag_rows["truncated"][f0:f0 + kk])
+                out.append((cc[i:i + kk], man[i:i + kk], r))
                 t += kk
                 want -= kk
-                nl += 1
-        return nl
+        return out
+
+    def run(calls, sink=None, m=None):
+        m = M if m is None else m
+        for c_, m_, r in calls:
+            if m == 0:
+                env.step_device(c_, m_)
+            elif sink is not None:
+                sink.launch(c_, m_)
+            else:
+                env.step_multi(c_, m_, rollout=r)
+                if r is not None and flag_rows is None:
+                    fold_flags(r["terminated"], r["truncated"])
+        return len(calls)
+
+    def issue(t0, cnt, sink=None, m=None):
+        """steps t0 .. t0+cnt-1 of the action stream, m per call (default: M); returns the number of calls"""
+        return run(plan(t0, cnt, m), sink, m)
 
     def timed(t0, cnt, sink=None, m=None):
         """cnt steps bracketed by barrier + synchronize on both sides; MAX over ranks of the wall time"""
@@ -311,11 +320,12 @@ def main():
             sink.wait()
         if dist is not None:
             dist.barrier()
+        calls = plan(t0, cnt, m)
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t_0 = time.perf_counter()
         ev0.record()
-        nl = issue(t0, cnt, sink, m)
+        nl = run(calls, sink, m)
         ev1.record()
         if sink is not None:
             sink.wait()
@@ -331,17 +341,27 @@ def main():
         return dt, ev_ms, nl
 
     # untimed pre-roll: the driver's short command (20 steps) would otherwise be measured while the clocks ramp up
+    # The seeded spawn queues are topped up ONCE, two thirds into the pre-roll (host work of several milliseconds during
+    # which the GPU idles and its clocks sag), and the GPU is then kept busy without a gap until the timed region starts;
+    # the queue (64 entries per env) is only consumed from there on, never wrapped (`config.spawn` says if it was).
     preroll = 0
     if args.preroll_ms > 0:
         chunk = max(M, 32)
-        t_end = time.perf_counter() + args.preroll_ms / 1e3
-        while time.perf_counter() < t_end:
+        t0_pre = time.perf_counter()
+        topped = False
+        while True:
+            el = (time.perf_counter() - t0_pre) * 1e3
+            if el >= args.preroll_ms:
+                break
+            if not topped and el >= args.preroll_ms * 0.66:
+                env.top_up_spawn_queue()
+                topped = True
             issue(preroll % period, chunk)
             preroll += chunk
             torch.cuda.synchronize()
-            env.top_up_spawn_queue()  # the seeded spawn streams continue past what the kernel consumed (never wraps)
+    else:
+        env.top_up_spawn_queue()
     issue(0, W)
-    env.top_up_spawn_queue()
     age_start = float(age.double().mean().item()) if (M >= 1 and roll is not None) else None
     if M >= 1 and roll is not None:
         flag_rows = {"t0": None, "terminated": torch.zeros((K, n), dtype=torch.uint8, device=device),
@@ -372,6 +392,10 @@ def main():
     if M >= 1 and not args.no_single_step:
         K1 = min(K, 256)
         env.top_up_spawn_queue()
+        t_w = time.perf_counter()  # (the top-up is host work: bring the clocks back up before timing)
+        while (time.perf_counter() - t_w) * 1e3 < min(args.preroll_ms, 60.0):
+            issue(0, 64, m=0)
+            torch.cuda.synchronize()
         issue(0, min(W, 16), m=0)
         dt1, ev1_ms, _ = timed(0, K1, m=0)
         single = {"value": world * n * K1 / dt1, "unit": "env-steps/s", "steps": K1, "ms_per_step": dt1 / K1 * 1e3,
@@ -467,10 +491,10 @@ def main():
                    "launches_timed": n_l, "preroll_steps": preroll,
                    "actions": "v~U(0.3,1) s~U(-1,1) maneuver~U{0..3}/64 steps, on device",
                    "autoreset": True,
-                   # the queue is topped up between the untimed calls; inside the timed region it may only be consumed
+                   # the queue is topped up once during the pre-roll; from there on it may only be consumed
                    "spawn": ("host queue (reference seed parity)" if max_cursor < env.spawn_queue_len else
-                             "host queue, WRAPPED inside the timed region (spawn nodes replayed: no seed parity)"),
-                   "resets_in_timed_region": n_resets, "max_respawns_of_one_env_in_timed_region": max_cursor,
+                             "host queue, WRAPPED since its top-up (spawn nodes replayed: no seed parity)"),
+                   "resets_since_queue_top_up": n_resets, "max_respawns_of_one_env_since_top_up": max_cursor,
                    "spawn_queue_len": env.spawn_queue_len,
                    # what the timed frames drew: draw lists of the last <= 3 dispatches of the timed region
                    "mean_segments_per_frame": drew["mean_segments_per_frame"] if drew else None,

@@ -424,31 +424,76 @@ struct PathInfo {
   int valid;              // 0: local_path was left untouched (early truncation) -> read it from the tables
 };
 
-// car.py:127-148.  EL = lanes that work on this env together: 64 (one wavefront per env, tid = lane) or a lane group
-// of the grouped simulate kernel (tid = lane within the group); it only matters for the U-turn search.
-template <int EL = 64>
-__device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuver, int& status, PathInfo& pi, const int tid) {
+// Where lanepath tracking reads the fat node records from: the map's table in global memory, or a copy of it in the
+// workgroup's LDS (the grouped simulate kernel: its tracking chain is 3-5 DEPENDENT record reads per step, and beside
+// the frame kernel a global load queues behind that kernel's store bursts on the same CU).
+struct FatGlobal {
+  const LpNode* fat;
+  const double2* nodes;
+  __device__ __forceinline__ LpNode get(int i) const { return fat[i]; }
+  __device__ __forceinline__ double2 pos(int i) const { return nodes[i]; }
+};
+struct FatLds {
+  const __attribute__((address_space(3))) int* base;  // records of sizeof(LpNode) bytes, 16-byte aligned
+  __device__ __forceinline__ LpNode get(int i) const {
+    union {
+      LpNode n;
+      int w[sizeof(LpNode) / 4];
+    } u;
+    const __attribute__((address_space(3))) int* p = base + i * (int)(sizeof(LpNode) / 4);
+#pragma unroll
+    for (int j = 0; j < (int)(sizeof(LpNode) / 4); j++) u.w[j] = p[j];  // (consecutive words: merged into 16-byte LDS reads)
+    return u.n;
+  }
+  __device__ __forceinline__ double2 pos(int i) const {
+    const __attribute__((address_space(3))) int* p = base + i * (int)(sizeof(LpNode) / 4);
+    return make_double2(__hiloint2double(p[1], p[0]), __hiloint2double(p[3], p[2]));
+  }
+};
+
+// The direction lanepath tracking starts from (car.py:128): orientation of the current edge turned by the maneuver
+template <class Fat>
+__device__ inline double d_maneuver_dir(const DevMap& m, const Fat& fat, const CarState& s, int maneuver) {
+  const int e0 = s.lp[0], e1 = s.lp[1];
+  const LpNode N0 = fat.get(e0);
+  return d_clip_angle(d_edge_ori_f(m, N0, e0, e1) + (maneuver * TC_PI) / 2);
+}
+
+// car.py:127-148.  EL = lanes that work on this env together: 64 (one wavefront per env, tid = lane), a lane group of the
+// grouped simulate kernel (tid = lane within the group), or 1 (one lane per env: the U-turn search of layer.py:59-74 was
+// made by the whole wavefront beforehand and its result is handed in as uturn_e / uturn_ed, -1 = no edge); it only
+// matters for the U-turn search.
+template <int EL = 64, class Fat = FatGlobal>
+__device__ inline int d_find_local_path(const DevMap& m, const Fat& fat, CarState& s, int maneuver, int& status, PathInfo& pi,
+                                        const int tid, const int uturn_e = -1, const int2 uturn_ed = make_int2(0, 0)) {
   double fx = s.front_x, fy = s.front_y;
   int e0 = s.lp[0], e1 = s.lp[1];
-  const LpNode N0 = m.lp_fat[e0], N1 = m.lp_fat[e1];
+  const LpNode N0 = fat.get(e0), N1 = fat.get(e1);
   double mdir = d_clip_angle(d_edge_ori_f(m, N0, e0, e1) + (maneuver * TC_PI) / 2);
   int ne0, ne1;
-  if (maneuver == 2 && s.last_maneuver != 2) {  // wave-uniform branch
-    int e = EL == 64 ? d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0, tid)
-                     : d_nearest_edge_with_orientation_g<(EL == 64 ? 32 : EL)>(m, fx, fy, mdir, 30.0, tid);
+  if (maneuver == 2 && s.last_maneuver != 2) {  // wave-uniform branch (per lane when EL == 1)
+    int e;
+    int2 ed;
+    if (EL == 1) {
+      e = uturn_e;
+      ed = uturn_ed;
+    } else {
+      e = EL == 64 ? d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0, tid)
+                   : d_nearest_edge_with_orientation_g<(EL == 64 || EL == 1 ? 32 : EL)>(m, fx, fy, mdir, 30.0, tid);
+      ed = e >= 0 ? m.lp_edges[e] : make_int2(0, 0);
+    }
     mdir = d_clip_angle(mdir + TC_PI);
     if (e < 0) {
       status |= 1;  // TC_S_UTURN_NO_EDGE
       return 1;
     }
-    int2 ed = m.lp_edges[e];
     ne0 = ed.x;
     ne1 = ed.y;
   } else {  // layer.py:77-103
     int nx = d_pick_next_f(m, N1, e1, mdir, status);
     int pv = d_pick_prev_f(m, N0, e0, mdir, status);
     if (nx < 0 || pv < 0) return 1;
-    double2 nn = m.lp_nodes[nx], np = m.lp_nodes[pv];
+    double2 nn = fat.pos(nx), np = fat.pos(pv);
     double d0 = d_dist(fx, fy, N0.x, N0.y), d1 = d_dist(fx, fy, N1.x, N1.y);
     double dn = d_dist(fx, fy, nn.x, nn.y), dp = d_dist(fx, fy, np.x, np.y);
     if (dn < d0 && dn < d1) {
@@ -468,7 +513,7 @@ __device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuv
   s.lp_len = 1;
   const bool fwd = s.velocity > 0;  // car.py:143
   int node = fwd ? ne1 : ne0;
-  LpNode A = m.lp_fat[node];
+  LpNode A = fat.get(node);
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     int nn = d_pick_next_f(m, A, node, mdir, status);
@@ -482,14 +527,14 @@ __device__ inline int d_find_local_path(const DevMap& m, CarState& s, int maneuv
       pi.ay = A.y;
       pi.ori = d_edge_ori_f(m, A, node, nn);
       if (!fwd) {  // the next record loaded is `node` again: fetch nn's position on its own
-        double2 q = m.lp_nodes[nn];
+        double2 q = fat.pos(nn);
         pi.bx = q.x;
         pi.by = q.y;
       }
     }
     if (fwd) {  // velocity > 0: continue from the new end node; otherwise from the same start node
       node = nn;
-      if (i < 2) A = m.lp_fat[node];
+      if (i < 2) A = fat.get(node);
       if (i == 0) {
         pi.bx = A.x;
         pi.by = A.y;
@@ -554,7 +599,8 @@ __device__ inline void d_car_kinematics(const DevCar& c, CarState& s, double v_i
 __device__ inline int d_car_step(const DevMap& m, const DevCar& c, CarState& s, double v_in, double s_in, int maneuver,
                                  int& status, PathInfo& pi, bool have_trig, const int tid) {
   d_car_kinematics(c, s, v_in, s_in, have_trig);
-  return d_find_local_path(m, s, maneuver, status, pi, tid);  // ONE call site: the function is ~2 k instructions inlined
+  const FatGlobal fg = {m.lp_fat, m.lp_nodes};
+  return d_find_local_path(m, fg, s, maneuver, status, pi, tid);  // ONE call site: the function is ~2 k instructions inlined
 }
 
 // ------------------------------------------------------------------ camera.py helpers
@@ -618,15 +664,43 @@ __device__ inline void r_hline(const Ras& r, int y, int xl, int xr) {
   }
 }
 
+// The same for a span that touches at most two consecutive words of its row -- any span when a row HAS only two words
+// (frames up to 64 pixels wide), or a span of at most 32 pixels: no loop, two ORs (the second with an empty mask when the
+// span stays inside one word)
+__device__ inline void r_hline_2w(const Ras& r, int y, int xl, int xr) {
+  xl = xl < 0 ? 0 : xl;
+  xr = xr > r.W - 1 ? r.W - 1 : xr;
+  const bool ok = (unsigned)(y - r.y0) < (unsigned)(r.y1 - r.y0) && xl <= xr;
+  const int w0 = xl >> 5, w1 = xr >> 5;
+  unsigned int* row = r.bits + (ok ? __mul24(y - r.y0, r.wpr) + w0 : 0);
+  const unsigned int lo = 0xffffffffu << (xl & 31), hi = 0xffffffffu >> (31 - (xr & 31));
+  const bool two = ok && w1 != w0;
+  atomicOr(&row[0], ok ? (two ? lo : (lo & hi)) : 0u);
+  atomicOr(&row[two ? 1 : 0], two ? hi : 0u);
+}
+
 // Filled circle (round cap) from its per-row half widths hw[|dy|], dy = -rad..rad: the pixel set of
 // Circle(center, rad, fill) is the union of centred spans, so per row only the widest one matters.
+// A centre more than 2^20 pixels away cannot reach a frame of at most 16384 x 16384 with rad < 32, whatever Circle()'s
+// 64-bit arithmetic makes of it; everything nearer is plain 32-bit arithmetic.
 __device__ inline void r_cap(const Ras& r, int cx, int cy, int rad, const unsigned char* hw, unsigned int hw4) {
+  const bool near = (unsigned)cx + (1u << 20) <= (2u << 20) && (unsigned)cy + (1u << 20) <= (2u << 20);
+  if (rad <= 15) {  // spans of at most 31 pixels
+    for (int dy = -rad; dy <= rad; dy++) {
+      const int ady = dy < 0 ? -dy : dy;
+      const int h = rad <= 3 ? (int)((hw4 >> (8 * ady)) & 255u) : (int)hw[ady];
+      const int y = cy + dy, xl = cx - h, xr = cx + h;
+      const bool ok = near && y >= 0 && y < r.H && xr >= 0 && xl < r.W;
+      r_hline_2w(r, ok ? y : -1, ok ? xl : 1, ok ? xr : 0);  // (at most 31 pixels: two words at most)
+    }
+    return;
+  }
   for (int dy = -rad; dy <= rad; dy++) {
     const int ady = dy < 0 ? -dy : dy;
-    const int h = rad <= 3 ? (int)((hw4 >> (8 * ady)) & 255u) : (int)hw[ady];
-    long long y = (long long)cy + dy, xl = (long long)cx - h, xr = (long long)cx + h;
-    const bool ok = y >= 0 && y < r.H && xr >= 0 && xl < r.W;
-    r_hline(r, ok ? (int)y : -1, ok ? (int)(xl < 0 ? 0 : xl) : 1, ok ? (int)(xr > r.W - 1 ? r.W - 1 : xr) : 0);
+    const int h = (int)hw[ady];
+    const int y = cy + dy, xl = cx - h, xr = cx + h;
+    const bool ok = near && y >= 0 && y < r.H && xr >= 0 && xl < r.W;
+    r_hline(r, ok ? y : -1, ok ? (xl < 0 ? 0 : xl) : 1, ok ? (xr > r.W - 1 ? r.W - 1 : xr) : 0);
   }
 }
 
@@ -967,7 +1041,10 @@ __device__ inline void r_fill_row(const Ras& r, int row, int np, int wmask, cons
   int xx1 = d_wrap32((xl + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
   int xx2 = d_wrap32((xr + (TC_XY_ONE >> 1)) >> TC_XY_SHIFT);
   const bool ok = xx2 >= 0 && xx1 < r.W;
-  r_hline(r, ok ? row : -1, xx1, xx2);
+  if (r.wpr <= 2)  // (wave-uniform) a row of at most 64 pixels: a clamped span touches at most its two words
+    r_hline_2w(r, ok ? row : -1, xx1, xx2);
+  else
+    r_hline(r, ok ? row : -1, xx1, xx2);
 }
 
 // Circle(center, radius, fill)

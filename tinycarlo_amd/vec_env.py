@@ -205,6 +205,7 @@ class TinyCarloVecEnv(gym.Env):
         self.track_fresh = False
         self.noise = (0, 0, 0)  # (n_blobs, max_radius, seed) of set_noise
         self.last_fresh: Optional[torch.Tensor] = None
+        self._shape_cache: Dict[int, Any] = {}
         self._step_serial = 0      # bumped by every reset / step launch: stale-info detection (LazyInfo)
         self._reserved_steps = 0   # tc_env_reserve_steps: scratch ring of K-step calls that render
 
@@ -585,7 +586,9 @@ class TinyCarloVecEnv(gym.Env):
             self.profile(1)
         r = nat.Rollout()
         if rollout:
-            want = self._rollout_shapes(K)
+            want = self._shape_cache.get(K)
+            if want is None:
+                want = self._shape_cache[K] = self._rollout_shapes(K)
             for k, t in rollout.items():
                 if k not in want:
                     raise ValueError(f"unknown rollout key {k!r}")

@@ -17,15 +17,43 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tinycarlo_amd", "csrc", "tinycarlo_hip.hip")
 
 
+# instructions that occupy the vector ALU for more than one pass of a wavefront (quarter rate on CDNA: 32-bit integer
+# multiplies, 64-bit multiply-adds, f64 transcendentals and conversions)
+SLOW = re.compile(r"^\s+v_(mul_lo_u32|mul_hi_u32|mul_hi_i32|mad_u64_u32|mad_i64_i32|rcp_f64|rsq_f64|sqrt_f64|div_fmas_f64|"
+                  r"div_scale_f64|div_fixup_f64|cvt_f64_\w+|cvt_\w+_f64|trunc_f64|rndne_f64|floor_f64|ldexp_f64|frexp_\w+)", re.M)
+
+
+def print_sections(s):
+    """static instruction mix between the probes (TSTAMP / MARK) of tc_frame_kernel, in code-layout order"""
+    m = re.search(r"^(_Z15tc_frame_kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", s, re.S | re.M)
+    body = m.group(2)
+    parts = re.split(r"^\s*; @@(TS \d+|MK [\w ]+)\s*$", body, flags=re.M)
+    print(f"{'section (from this probe to the next, layout order)':54s} {'v_*':>6s} {'slow':>5s} {'s_*':>6s} {'ds_*':>5s} {'vmem':>5s} {'v_mov':>6s} {'cndmask':>7s}")
+    tot = [0] * 7
+    names = ["entry"] + parts[1::2]
+    for name, txt in zip(names, parts[0::2]):
+        row = (len(re.findall(r"^\s+v_", txt, re.M)), len(SLOW.findall(txt)), len(re.findall(r"^\s+s_", txt, re.M)),
+               len(re.findall(r"^\s+ds_", txt, re.M)), len(re.findall(r"^\s+(?:global_|buffer_|flat_|scratch_)", txt, re.M)),
+               len(re.findall(r"^\s+v_mov_b", txt, re.M)), len(re.findall(r"^\s+v_cndmask", txt, re.M)))
+        tot = [a + b for a, b in zip(tot, row)]
+        print(f"{name:54s} {row[0]:6d} {row[1]:5d} {row[2]:6d} {row[3]:5d} {row[4]:5d} {row[5]:6d} {row[6]:7d}")
+    print(f"{'total':54s} {tot[0]:6d} {tot[1]:5d} {tot[2]:6d} {tot[3]:5d} {tot[4]:5d} {tot[5]:6d} {tot[6]:7d}")
+
+
 def main():
-    args = [a for a in sys.argv[1:] if a != "--full"]
+    args = [a for a in sys.argv[1:] if a not in ("--full", "--sections")]
     full = "--full" in sys.argv[1:]
+    sections = "--sections" in sys.argv[1:]
+    if sections:
+        args.append("-DTC_MARKERS")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "tc.s")
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-disable-machine-licm",
                "-std=c++17", "-S", "--cuda-device-only", "-o", out, SRC] + ([] if full else ["-DTC_DEV_FAST"]) + args
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         s = open(out).read()
+    if sections:
+        return print_sections(s)
     # static instruction counts per kernel body
     counts = {}
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", s, re.S | re.M):
