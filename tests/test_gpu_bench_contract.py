@@ -32,8 +32,8 @@ def test_default_workload_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     # K-step calls: simulate launches + launches over the frames; the roofline kernel is the one writing the frames
-    assert r["launches_per_call"] == "tc_envl_kernel+tc_frame_kernel" and r["kernel"] == "tc_frame_kernel"
-    assert set(r["kernels_us"]) == {"tc_envl_kernel", "tc_frame_kernel"} and all(v > 0 for v in r["kernels_us"].values())
+    assert r["launches_per_call"] == "tc_envg_kernel+tc_frame_kernel" and r["kernel"] == "tc_frame_kernel"
+    assert set(r["kernels_us"]) == {"tc_envg_kernel", "tc_frame_kernel"} and all(v > 0 for v in r["kernels_us"].values())
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     assert r["algorithmic_bytes_per_env_step"] == 240 + 5 * 64 * 64
     # 40 steps at up to 128 per call = ONE tc_step_multi call of 40 steps, pipelined inside as 4 chunks of 10; the

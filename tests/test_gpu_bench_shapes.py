@@ -1,7 +1,7 @@
 """The path the benchmark times, at the benchmark's own shapes, against the CPU oracle -- and every shipped switch.
 
 `bench.py` issues tc_step_multi calls with a rollout of observations: 16-step chunks on one frame stream, first chunk
-through tc_env_kernel<K,false>, the rest through tc_envl_kernel (one lane per env), frames by tc_frame_kernel, scratch in a ring of three
+through tc_env_kernel<K,false>, the rest through tc_envg_kernel, frames by tc_frame_kernel, scratch in a ring of three
 chunks (include/tinycarlo_hip.h: tc_step_multi / tc_env_reserve_steps).  The loop it replaces is the caller's
 `while: env.step(action)` (/root/reference/examples/stanley_control.py:50-60 around tinycarlo/env.py:115-147), K times.
 
@@ -108,14 +108,14 @@ def test_cfg3_bench_shape_4096_envs_64_steps():
     """cfg3 as bench.py runs it: 4096 envs, simple_layout, 64x64 classes, autoreset, 64-step calls = 4 chunks of 16 on one
     frame stream (per-env first chunk, grouped rest, ring slot 0 reused by chunk 3); two calls back to back"""
     n_reset, info = run_case("simple_layout", "r64", "classes", 4096, 64, calls=2)
-    assert info["kernel"] == "tc_envl_kernel+tc_frame_kernel" and info["steps_per_dispatch"] == 16, info
+    assert info["kernel"] == "tc_envg_kernel+tc_frame_kernel" and info["steps_per_dispatch"] == 16, info
     assert n_reset > 0, "no env re-spawned inside the calls"
 
 
 def test_cfg4_bench_shape_knuffingen_r128():
     """cfg4's shape: knuffingen, 128x128 classes (K = 9 frame kernel, two camera layer groups), 512 envs x 32 steps"""
     n_reset, info = run_case("knuffingen", "r128", "classes", 512, 32)
-    assert info["kernel"] == "tc_envl_kernel+tc_frame_kernel" and info["kvar"] == 9, info
+    assert info["kernel"] == "tc_envg_kernel+tc_frame_kernel" and info["kvar"] == 9, info
 
 
 def test_cfg5_bench_shape_knuffingen_480x640_rgb_banded():
@@ -123,7 +123,7 @@ def test_cfg5_bench_shape_knuffingen_480x640_rgb_banded():
     (bench.py's steps_per_launch for cfg5), then 6 more steps in a second call"""
     n_reset, info = run_case("knuffingen", "r480", "rgb", 8, 2, actions=mixed_actions, calls=1, threads=8)
     n_reset, info = run_case("knuffingen", "r480", "rgb", 8, 6, actions=bench_actions, calls=2, threads=8)
-    assert info["kernel"] == "tc_envl_kernel+tc_frame_kernel", info
+    assert info["kernel"] == "tc_envg_kernel+tc_frame_kernel", info
 
 
 # every switch the shipped library reads (INTEGRATION.md calls them result-neutral): forced one at a time, same oracle
@@ -133,10 +133,6 @@ SWITCHES = [
     {"TC_SEG_LDS_CAP": "3"},              # every frame mixes an LDS head (3 segments) with a global tail
     {"TC_FRAME_STREAMS": "1"},
     {"TC_FIRST_CHUNK_PER_ENV": "0"},
-    {"TC_SIM_PERSIST": "0"},              # a simulate launch per chunk (tc_env_kernel first, then tc_envg_kernel) instead of one per call
-    {"TC_SIM_PERSIST": "0", "TC_CHUNK": "0"},  # ... chunks one after the other: tc_envl_kernel per chunk
-    {"TC_ENV_LANE": "0"},                 # the 8-lanes-per-env simulate kernel (tc_envg_kernel) instead of one lane per env
-    {"TC_ENV_LANE": "0", "TC_ENVG_MAP_LDS": "0"},
     {"TC_ENV_GROUPED": "0"},              # tc_env_kernel<K,false> for every chunk, not pipelined
     {"TC_ENVG_MAP_LDS": "0"},
     {"TC_CHUNK": "0"},                    # chunks follow each other on the caller's stream
@@ -162,7 +158,7 @@ def test_every_switch_gives_the_oracle_rollout(switch, monkeypatch):
         assert info["kernel"] == "tc_env_kernel+tc_raster_kernel", info
 
 
-@pytest.mark.parametrize("switch", [{}, {"TC_GROUPS": "0"}, {"TC_SEG_LDS_CAP": "5"}, {"TC_ENV_GROUPED": "0"}, {"TC_ENV_LANE": "0"}],
+@pytest.mark.parametrize("switch", [{}, {"TC_GROUPS": "0"}, {"TC_SEG_LDS_CAP": "5"}, {"TC_ENV_GROUPED": "0"}, {"TC_ENVG_MAP_LDS": "0"}],
                          ids=lambda s: ",".join(f"{k}={v}" for k, v in s.items()) or "defaults")
 def test_switches_on_knuffingen(switch, monkeypatch):
     """the switches that only matter on a map with camera layer groups / the K = 13 windowed path"""

@@ -95,12 +95,10 @@ def test_displaced_positions_single_step_kernel(mp):
     env.close()
 
 
-@pytest.mark.parametrize("lane", ["1", "0"])
 @pytest.mark.parametrize("mp,res", [("simple_layout", "r64"), ("knuffingen", "r64")])
-def test_displaced_positions_grouped_kernel(mp, res, lane, monkeypatch):
-    """the same through tc_step_multi with an observation rollout, 3 steps, envs of one wavefront in and outside the grid
-    side by side: tc_envl_kernel (one lane per env, TC_ENV_LANE=1) and tc_envg_kernel (8 lanes per env)"""
-    monkeypatch.setenv("TC_ENV_LANE", lane)
+def test_displaced_positions_grouped_kernel(mp, res):
+    """the same through tc_step_multi with an observation rollout (tc_envg_kernel: 8 lanes per env, envs of one wavefront
+    in and outside the grid side by side), 3 steps"""
     d = golden(f"single_{mp}.npz")
     pre0 = _states_from(d, "pre_")
     rng = np.random.default_rng(12)
@@ -120,7 +118,7 @@ def test_displaced_positions_grouped_kernel(mp, res, lane, monkeypatch):
     mank = np.repeat(man[None], K, axis=0)
     roll = env.alloc_rollout(K, keys=("obs", "reward", "terminated", "truncated", "cte"))
     env.step_multi(torch.from_numpy(cck).cuda(), torch.from_numpy(mank.astype(np.int32)).cuda(), rollout=roll)
-    assert env.launch_info(K)["kernel"].startswith("tc_envl_kernel" if lane == "1" else "tc_envg_kernel") or mp != "simple_layout"
+    assert env.launch_info(K)["kernel"].startswith("tc_envg_kernel") or mp != "simple_layout"
     C = env.n_classes
     for k in range(K):
         o.step(cc, man, flags=orc.F_WRAPPED, with_obs=True)

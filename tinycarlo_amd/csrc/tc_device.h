@@ -451,42 +451,25 @@ struct FatLds {
   }
 };
 
-// The direction lanepath tracking starts from (car.py:128): orientation of the current edge turned by the maneuver
-template <class Fat>
-__device__ inline double d_maneuver_dir(const DevMap& m, const Fat& fat, const CarState& s, int maneuver) {
-  const int e0 = s.lp[0], e1 = s.lp[1];
-  const LpNode N0 = fat.get(e0);
-  return d_clip_angle(d_edge_ori_f(m, N0, e0, e1) + (maneuver * TC_PI) / 2);
-}
-
-// car.py:127-148.  EL = lanes that work on this env together: 64 (one wavefront per env, tid = lane), a lane group of the
-// grouped simulate kernel (tid = lane within the group), or 1 (one lane per env: the U-turn search of layer.py:59-74 was
-// made by the whole wavefront beforehand and its result is handed in as uturn_e / uturn_ed, -1 = no edge); it only
-// matters for the U-turn search.
+// car.py:127-148.  EL = lanes that work on this env together: 64 (one wavefront per env, tid = lane) or a lane group
+// of the grouped simulate kernel (tid = lane within the group); it only matters for the U-turn search.
 template <int EL = 64, class Fat = FatGlobal>
 __device__ inline int d_find_local_path(const DevMap& m, const Fat& fat, CarState& s, int maneuver, int& status, PathInfo& pi,
-                                        const int tid, const int uturn_e = -1, const int2 uturn_ed = make_int2(0, 0)) {
+                                        const int tid) {
   double fx = s.front_x, fy = s.front_y;
   int e0 = s.lp[0], e1 = s.lp[1];
   const LpNode N0 = fat.get(e0), N1 = fat.get(e1);
   double mdir = d_clip_angle(d_edge_ori_f(m, N0, e0, e1) + (maneuver * TC_PI) / 2);
   int ne0, ne1;
-  if (maneuver == 2 && s.last_maneuver != 2) {  // wave-uniform branch (per lane when EL == 1)
-    int e;
-    int2 ed;
-    if (EL == 1) {
-      e = uturn_e;
-      ed = uturn_ed;
-    } else {
-      e = EL == 64 ? d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0, tid)
-                   : d_nearest_edge_with_orientation_g<(EL == 64 || EL == 1 ? 32 : EL)>(m, fx, fy, mdir, 30.0, tid);
-      ed = e >= 0 ? m.lp_edges[e] : make_int2(0, 0);
-    }
+  if (maneuver == 2 && s.last_maneuver != 2) {  // wave-uniform branch
+    int e = EL == 64 ? d_nearest_edge_with_orientation(m, fx, fy, mdir, 30.0, tid)
+                     : d_nearest_edge_with_orientation_g<(EL == 64 ? 32 : EL)>(m, fx, fy, mdir, 30.0, tid);
     mdir = d_clip_angle(mdir + TC_PI);
     if (e < 0) {
       status |= 1;  // TC_S_UTURN_NO_EDGE
       return 1;
     }
+    int2 ed = m.lp_edges[e];
     ne0 = ed.x;
     ne1 = ed.y;
   } else {  // layer.py:77-103

@@ -199,9 +199,6 @@ __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)"
 // loads, nor hoisted out of the loop the call sits in -- they are s_load'ed where they are used.
 template <class T>
 __device__ __forceinline__ const T& kernarg_again(const T& r) {
-#ifdef TC_KA_OFF
-  return r;  // experiment: no re-read (the compiler keeps or spills what it loaded before)
-#endif
   unsigned long long p = (unsigned long long)&r;
   asm volatile("" : "+s"(p));
   return *(const T*)(const __attribute__((address_space(4))) T*)p;
@@ -360,11 +357,8 @@ __device__ __forceinline__ void d_apply_terms(const tc_term* terms, int n_terms,
 
 // The same stack for the grouped simulate kernel, where every lane of an env's group runs it: distances and counters
 // of the env sit in a small LDS record (all lanes of the group read and write the same words with the same values).
-// (st: element stride of cnt[] and dist[] -- 1 for a record per env, the workgroup size when the records of a workgroup's
-// envs are interleaved so that the lanes of a wavefront hit different LDS banks)
 __device__ __forceinline__ void d_apply_terms_mem(const tc_term* terms, int n_terms, int* cnt, double tw, int C, double cte,
-                                                  double vel, const double* dist, double& reward, int& terminated,
-                                                  const int st = 1) {
+                                                  double vel, const double* dist, double& reward, int& terminated) {
   const double half = tw / 2;
   for (int t = 0; t < n_terms; t++) {
     const tc_term* T = terms + t;
@@ -373,10 +367,10 @@ __device__ __forceinline__ void d_apply_terms_mem(const tc_term* terms, int n_te
     if (kind == TC_T_LANELINE_SPARSE_REWARD) {  // reward.py:20-21, utils.py:15-19
       double local = 0.0;
       for (int l = 0; l < C; l++)
-        if (((mask >> l) & 1u) && dist[l * st] < half) local += T->per_layer[l];
+        if (((mask >> l) & 1u) && dist[l] < half) local += T->per_layer[l];
       reward = reward + local;
     } else if (kind == TC_T_LANELINE_LINEAR_REWARD) {  // reward.py:40-41
-      for (int l = 0; l < C; l++) reward = reward + d_linear_reward(dist[l * st], tw, T->per_layer[l], 0.0);
+      for (int l = 0; l < C; l++) reward = reward + d_linear_reward(dist[l], tw, T->per_layer[l], 0.0);
     } else if (kind == TC_T_CTE_SPARSE_REWARD) {  // reward.py:60
       double local = 0.0;
       if (tc_fabs(cte) <= T->p[0]) local += T->p[1];
@@ -385,10 +379,10 @@ __device__ __forceinline__ void d_apply_terms_mem(const tc_term* terms, int n_te
       reward = reward + d_linear_reward(cte, T->p[0], T->p[1], T->p[2]);
     } else if (kind == TC_T_LANELINE_CROSSING_TERMINATION) {  // termination.py:19-21
       for (int l = 0; l < C; l++)
-        if (((mask >> l) & 1u) && dist[l * st] <= half) terminated = 1;
+        if (((mask >> l) & 1u) && dist[l] <= half) terminated = 1;
     } else if (kind == TC_T_CTE_TERMINATION || kind == TC_T_CRASH_TERMINATION) {  // termination.py:39-47,61-69
       const bool cond = kind == TC_T_CTE_TERMINATION ? (tc_fabs(cte) > T->p[0]) : (tc_fabs(vel) < T->p[0]);
-      int c = cnt[t * st];
+      int c = cnt[t];
       if (cond) {
         c += 1;
         if (c >= T->number_of_steps) {
@@ -398,7 +392,7 @@ __device__ __forceinline__ void d_apply_terms_mem(const tc_term* terms, int n_te
       } else {
         c = 0;
       }
-      cnt[t * st] = c;
+      cnt[t] = c;
     }
   }
 }
@@ -1405,15 +1399,6 @@ struct MultiArgs {
                       // copied into the workgroup's LDS at kernel start and phase B reads them from there
   int fat_lds;        // tc_envg_kernel: 1 = the lanepath's fat node records (96 bytes per node) sit in LDS too, behind the
                       // edge records (or at offset 0 without them), and lanepath tracking reads them there
-  // tc_envl_kernel launched ONCE for a whole pipelined call: after the last step of every `chunk` steps each workgroup
-  // arrives at arrive[G & 63] (G = g0 + chunk index: the handle's running chunk number) and the last of the n_wg
-  // workgroups publishes G + 1 in *progress -- the value the frame launches of that chunk wait for on their stream
-  // (hipStreamWaitValue32).  progress == NULL: a launch per chunk, nothing published.
-  int chunk;
-  unsigned int* progress;
-  int* arrive;
-  unsigned int g0;
-  int n_wg;
   tc_rollout roll;
 };
 __device__ __forceinline__ RollStep roll_at(const tc_rollout& r, size_t row0, int C) {
@@ -1574,11 +1559,6 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
     TSTAMP(9);
 #ifdef TC_TIMING_LDS
     TSTAMP(26);  // back to back with probe 9: what a probe costs
-    {  // experiment: a re-read of the argument block right here
-      const RArgs& q = kernarg_again(a0);
-      if (q.cam.n_bands >= 0) TSTAMP(23);
-      if (q.cam.thickness >= 0) TSTAMP(28);
-    }
 #endif
     Ras r;
     r.W = W;
@@ -2627,18 +2607,6 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
       }
     }
     TSTAMP(15);
-    if (sa.ma.progress && ((k + 1) % sa.ma.chunk == 0 || k + 1 == nsteps)) {
-      // one launch for the whole call (see MultiArgs): end of a chunk -- this workgroup's pose rows are visible
-      // device-wide, then it arrives; the last workgroup publishes the chunk number the frame launches wait for
-      __threadfence();
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const unsigned int G = sa.ma.g0 + (unsigned int)(k / sa.ma.chunk);
-        const int old = atomicAdd(sa.ma.arrive + (G & 63u), 1);
-        if (old == (int)((G >> 6) + 1u) * sa.ma.n_wg - 1)
-          __hip_atomic_store(sa.ma.progress, G + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
   }
   // ---- state and the last step's outputs back to the caller's buffers
   const StepArgs& s1 = step_args();
@@ -2668,420 +2636,6 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
   if (live && s1.a.term_counters && sub < s1.a.n_terms) s1.a.term_counters[(size_t)env * TC_MAX_TERMS + sub] = gl.cnt[sub];
 }
 
-// ---------------------------------------------------------------------------------------------
-// Lane-per-env simulate kernel for K-step calls: ONE lane per env, 64 envs per wavefront, 256 per workgroup.
-// Why: the grouped kernel above (8 lanes per env) keeps 512 wavefronts -- each with ~128 VGPRs, one of the four wave slots
-// of its SIMD, and 35 KB of LDS per workgroup -- resident for a whole chunk, because a step is a latency chain (~29 us
-// beside the frame kernel) that no amount of lanes shortens; measured, the frame kernel loses ~12 % of its capacity to
-// it (frames of a 16-step chunk: 435 us alone, 510 us beside it).  With one lane per env the same chain runs in 64
-// wavefronts (16 workgroups on 16 CUs): phase A is ordinary SIMT code over 64 envs (divergent where envs take
-// different branches), phase B is a per-lane loop over the candidate edges of the car's grid cell with the edge records
-// in LDS -- no cross-lane reduction at all -- and every global access is lane-coalesced (actions, rollout rows, state).
-// The one wavefront-wide piece is the first step of a U-turn (layer.py:59-74, an argmin over ALL lanepath edges): the
-// envs that need it are served one after the other by all 64 lanes together, from an LDS copy of the lanepath edges.
-// Results are bit-identical to the other simulate kernels (same device functions, same operation order per env).
-#define TC_ENVL_NT 256
-struct EnvlLds {  // dynamic LDS layout (bytes from the block's start), 16-byte aligned pieces
-  int off_exy, off_ofw, off_orv, off_fat, off_lpo, off_lpxy, off_lped, off_dist, off_cnt, total;
-};
-__device__ __forceinline__ EnvlLds envl_layout(int TE, int lpN, int lpE, int C) {
-  EnvlLds L;
-  int o = 0;
-  L.off_exy = o;  o += TE * 32;
-  L.off_ofw = o;  o += TE * 8;
-  L.off_orv = o;  o += TE * 8;
-  o = (o + 15) / 16 * 16;
-  L.off_fat = o;  o += lpN * (int)sizeof(LpNode);
-  L.off_lpo = o;  o += lpE * 8;
-  o = (o + 15) / 16 * 16;
-  L.off_lpxy = o; o += lpE * 32;
-  L.off_lped = o; o += lpE * 8;
-  o = (o + 15) / 16 * 16;
-  L.off_dist = o; o += C * TC_ENVL_NT * 8;           // laneline distances of the step, [layer][lane]
-  L.off_cnt = o;  o += TC_MAX_TERMS * TC_ENVL_NT * 4;  // consecutive-step counters of the terms, [slot][lane]
-  L.total = (o + 15) / 16 * 16;
-  return L;
-}
-static size_t envl_lds_bytes(const DevMap& m) {
-  size_t o = (size_t)m.total_edges * 48;
-  o = (o + 15) / 16 * 16;
-  o += (size_t)m.lpN * sizeof(LpNode) + (size_t)m.lpE * 8;
-  o = (o + 15) / 16 * 16;
-  o += (size_t)m.lpE * 40;
-  o = (o + 15) / 16 * 16;
-  o += (size_t)m.C * TC_ENVL_NT * 8 + (size_t)TC_MAX_TERMS * TC_ENVL_NT * 4;
-  return (o + 15) / 16 * 16;
-}
-typedef __attribute__((address_space(3))) double* LdsDoubleW;
-typedef __attribute__((address_space(3))) int* LdsIntW;
-__global__ __launch_bounds__(TC_ENVL_NT) void tc_envl_kernel(StepArgs sa_unused) {
-  extern __shared__ __align__(16) unsigned char gsm[];
-  __builtin_amdgcn_s_setprio(TC_ENVG_PRIO);  // (a latency chain beside the frame kernel's wavefronts: see tc_envg_kernel)
-  const StepArgs& s0 = step_args();
-  const int lane = threadIdx.x;
-  const int N = s0.a.N;
-  const EnvlLds LL = envl_layout(s0.a.m.total_edges, s0.a.m.lpN, s0.a.m.lpE, s0.a.m.C);
-  const LdsDouble l_exy = (LdsDouble)(gsm + LL.off_exy), l_ofw = (LdsDouble)(gsm + LL.off_ofw), l_orv = (LdsDouble)(gsm + LL.off_orv);
-  const LdsDouble l_lpo = (LdsDouble)(gsm + LL.off_lpo), l_lpxy = (LdsDouble)(gsm + LL.off_lpxy);
-  const __attribute__((address_space(3))) int* l_lped = (const __attribute__((address_space(3))) int*)(gsm + LL.off_lped);
-  const FatLds fl = {(const __attribute__((address_space(3))) int*)(gsm + LL.off_fat)};
-  {  // the map into LDS, once per launch: lane-line edge records, fat lanepath nodes, lanepath edges (orientation, end points)
-    const DevMap& m0 = s0.a.m;
-    LdsDoubleW w4 = (LdsDoubleW)(gsm + LL.off_exy), wf = (LdsDoubleW)(gsm + LL.off_ofw), wr = (LdsDoubleW)(gsm + LL.off_orv);
-    for (int i = lane; i < m0.total_edges; i += TC_ENVL_NT) {
-      const double4 q = m0.edge_xy[i];
-      w4[4 * i] = q.x;
-      w4[4 * i + 1] = q.y;
-      w4[4 * i + 2] = q.z;
-      w4[4 * i + 3] = q.w;
-      wf[i] = m0.ori_fwd[i];
-      wr[i] = m0.ori_rev[i];
-    }
-    const int* src = (const int*)m0.lp_fat;
-    LdsIntW dst = (LdsIntW)(gsm + LL.off_fat);
-    const int nw = m0.lpN * (int)(sizeof(LpNode) / 4);
-    for (int i = lane; i < nw; i += TC_ENVL_NT) dst[i] = src[i];
-    LdsDoubleW wo = (LdsDoubleW)(gsm + LL.off_lpo), wxy = (LdsDoubleW)(gsm + LL.off_lpxy);
-    LdsIntW wed = (LdsIntW)(gsm + LL.off_lped);
-    for (int i = lane; i < m0.lpE; i += TC_ENVL_NT) {
-      const int2 ed = m0.lp_edges[i];
-      const double2 a = m0.lp_nodes[ed.x], b = m0.lp_nodes[ed.y];
-      wo[i] = m0.lp_ori[i];
-      wxy[4 * i] = a.x;
-      wxy[4 * i + 1] = a.y;
-      wxy[4 * i + 2] = b.x;
-      wxy[4 * i + 3] = b.y;
-      wed[2 * i] = ed.x;
-      wed[2 * i + 1] = ed.y;
-    }
-    __syncthreads();
-  }
-  int env = s0.a.env0 + blockIdx.x * TC_ENVL_NT + lane;
-  const bool live = env < N;  // lanes past the last env compute on a copy of it and store nothing
-  env = live ? env : N - 1;
-  double* my_dist = (double*)(gsm + LL.off_dist) + lane;  // element l at my_dist[l * TC_ENVL_NT]
-  int* my_cnt = (int*)(gsm + LL.off_cnt) + lane;
-  CarState s;
-  int nr = 0, cursor = 0, cursor0 = 0;
-  bool have_trig = false;
-  {
-    const tc_buffers& b = s0.a.b;
-    s.x = b.x[env];
-    s.y = b.y[env];
-    s.theta = b.theta[env];
-    s.velocity = b.velocity[env];
-    s.steering = b.steering[env];
-    s.radius = b.radius[env];
-    s.front_x = b.front_x[env];
-    s.front_y = b.front_y[env];
-    s.cth = s.sth = 0;
-    const int4 lp0 = ((const int4*)b.local_path)[2 * env], lp1 = ((const int4*)b.local_path)[2 * env + 1];
-    s.lp[0] = lp0.x; s.lp[1] = lp0.y; s.lp[2] = lp0.z; s.lp[3] = lp0.w;
-    s.lp[4] = lp1.x; s.lp[5] = lp1.y; s.lp[6] = lp1.z; s.lp[7] = lp1.w;
-    s.lp_len = b.lp_len[env];
-    s.last_maneuver = b.last_maneuver[env];
-    if (s0.flags & TC_F_AUTORESET) {
-      nr = b.needs_reset[env];
-      cursor = cursor0 = b.spawn_cursor[env];
-    }
-    for (int t = 0; t < TC_MAX_TERMS; t++)
-      my_cnt[t * TC_ENVL_NT] = (s0.a.n_terms > 0 && s0.a.term_counters) ? s0.a.term_counters[(size_t)env * TC_MAX_TERMS + t] : 0;
-  }
-  double cte = 0, he = 0, reward = 0;
-  int terminated = 0, trunc = 0, status = 0;
-  const int nsteps = s0.ma.nsteps;
-  // the action of step k+1 is fetched at the top of step k (see tc_envg_kernel); here the loads are lane-coalesced
-  double2 act_d = make_double2(0.0, 0.0);
-  float2 act_f = make_float2(0.f, 0.f);
-  int act_m = 0;
-  auto fetch_action = [&](int kk) {
-    const StepArgs& sq = step_args();
-    const size_t r = (size_t)kk * sq.a.N + env;
-    if (sq.cdtype == TC_F32)
-      act_f = ((const float2*)sq.car_control)[r];
-    else
-      act_d = ((const double2*)sq.car_control)[r];
-    act_m = sq.maneuver[r];
-  };
-  fetch_action(0);
-  for (int k = 0; k < nsteps; k++) {
-    const StepArgs& sa = step_args();  // re-read per step: see step_args()
-    const KArgs& a = sa.a;
-    const DevMap& m = a.m;
-    const tc_buffers& b = a.b;
-    const unsigned int flags = sa.flags;
-    const size_t row0 = (size_t)k * a.N;
-    const RollStep roll = roll_at(sa.ma.roll, row0, a.m.C);
-    status = 0;
-    trunc = 0;
-    const double2 cur_d = act_d;
-    const float2 cur_f = act_f;
-    const int cur_m = act_m;
-    fetch_action(k + 1 < nsteps ? k + 1 : k);
-    PathInfo pinfo;
-    pinfo.ax = pinfo.ay = pinfo.bx = pinfo.by = pinfo.ori = 0;
-    pinfo.valid = 0;
-    bool fresh = false;
-    // which of the three things a step can be (car.py:34-44 re-spawn / not steppable / car.py:70-148)
-    const bool respawn = (flags & TC_F_AUTORESET) && nr;
-    const bool unreset = !respawn && ((unsigned)s.lp[0] >= (unsigned)m.lpN || (unsigned)s.lp[1] >= (unsigned)m.lpN);
-    const bool drive = !respawn && !unreset;
-    if (respawn) {
-      const int cur = cursor;
-      int node;
-      if ((flags & TC_F_DEVICE_SPAWN) && a.spawn_n > 0) {
-        node = a.spawn_tab[tc_spawn_index(a.spawn_seed, (uint32_t)env, (uint32_t)cur, (uint32_t)a.spawn_n)];
-      } else {
-        if ((unsigned)cur >= (unsigned)b.spawn_queue_len) status |= TC_S_SPAWN_WRAPPED;
-        node = b.spawn_queue[(size_t)env * b.spawn_queue_len + ((unsigned)cur % (unsigned)b.spawn_queue_len)];
-      }
-      int nd = node;
-      if (!((unsigned)nd < (unsigned)m.lpN && fl.get(nd).nnext > 0)) {  // checked_spawn() on the LDS copy
-        status |= TC_S_BAD_SPAWN;
-        nd = m.first_spawnable;
-      }
-      {  // d_reset() from the LDS copy of the fat node
-        const LpNode F = fl.get(nd);
-        s.x = F.x;
-        s.y = F.y;
-        s.theta = F.next_ori[0];
-#pragma unroll
-        for (int i = 0; i < 8; i++) s.lp[i] = -1;
-        s.lp[0] = nd;
-        s.lp[1] = F.next[0];
-        s.lp_len = 1;
-        d_update_front(a.car, s);
-        s.steering = 0.0;
-        s.radius = 0.0;
-        s.velocity = 0.0;
-        s.last_maneuver = 0;
-      }
-      fresh = true;
-      have_trig = true;
-      cursor = cur + 1;
-    } else if (unreset) {
-      status |= TC_S_NOT_RESET;
-      trunc = 1;
-    }
-    // ---- car.py:70-125 for the lanes that drive (the others sit the code out: plain SIMT divergence)
-    int man = 0;
-    if (drive) {
-      double v, st;
-      if (sa.cdtype == TC_F32) {
-        v = (double)cur_f.x;
-        st = (double)cur_f.y;
-      } else {
-        v = cur_d.x;
-        st = cur_d.y;
-      }
-      v = d_np_clip(v, -1.0, 1.0);  // env.py:118
-      st = d_np_clip(st, -1.0, 1.0);
-      man = cur_m;
-      d_car_kinematics(a.car, s, v, st, have_trig);
-    }
-    // ---- first step of a U-turn (car.py:129-131, layer.py:59-74): every env that needs the search gets it from the whole
-    // wavefront, one env after the other; lane j of the ballot keeps its result
-    const bool need_ut = live && drive && man == 2 && s.last_maneuver != 2;
-    int ut_e = -1;
-    int2 ut_ed = make_int2(0, 0);
-    {
-      unsigned long long need = __ballot(need_ut);
-      if (need) {
-        const double my_dir = need_ut ? d_maneuver_dir(m, fl, s, man) : 0.0;
-        const double lim = d_radians(30.0);
-        const int wl = lane & (TC_NT - 1);
-        while (need) {
-          const int j = __builtin_ctzll(need);
-          need &= need - 1;
-          const double px = d_readlane(s.front_x, j), py = d_readlane(s.front_y, j), dir = d_readlane(my_dir, j);
-          int best = -1;
-          double bd = 0;
-          for (int e = wl; e < m.lpE; e += TC_NT) {
-            if (!(tc_fabs(d_clip_angle(l_lpo[e] - dir)) <= lim)) continue;
-            const double d = tc_fabs(d_dist(px, py, l_lpxy[4 * e], l_lpxy[4 * e + 1]) + d_dist(px, py, l_lpxy[4 * e + 2], l_lpxy[4 * e + 3]));
-            if (best < 0 || d < bd) {
-              best = e;
-              bd = d;
-            }
-          }
-          wave_argmin(bd, best);
-          if (wl == j) ut_e = best;
-        }
-        if (ut_e >= 0) ut_ed = make_int2(l_lped[2 * ut_e], l_lped[2 * ut_e + 1]);
-      }
-    }
-    if (drive) {
-      trunc = d_find_local_path<1>(m, fl, s, man, status, pinfo, 0, ut_e, ut_ed);
-      have_trig = true;
-    }
-    // ---- info (car.py:46-53), default reward / termination (env.py:93,99)
-    const bool have_info = !fresh && s.lp_len >= 2;
-    cte = 0;
-    he = 0;
-    if (have_info && !pinfo.valid) {  // path kept from an earlier step (truncated before it was rebuilt)
-      const double2 n1 = fl.pos(s.lp[2]), n2 = fl.pos(s.lp[3]);
-      pinfo.ax = n1.x;
-      pinfo.ay = n1.y;
-      pinfo.bx = n2.x;
-      pinfo.by = n2.y;
-      pinfo.ori = d_edge_ori_f(m, fl.get(s.lp[2]), s.lp[2], s.lp[3]);
-    }
-    if (have_info) {
-      cte = d_distance_to_edge(pinfo.ax, pinfo.ay, pinfo.bx, pinfo.by, s.front_x, s.front_y);
-      he = d_clip_angle(pinfo.ori - s.theta);
-    }
-    reward = 0;
-    terminated = 0;
-    if (!(flags & TC_F_WRAPPED) && !fresh) {
-      double r = (-1 / a.car.track_width) * cte + 1;
-      reward = (0 > r) ? 0 : r;
-      terminated = cte > (a.car.track_width * 10);
-    }
-    // ---- phase B: nearest lane-line edge and distance per layer (car.py:55-64, layer.py:33-44,126-164): this lane walks
-    // the candidate lists of its own grid cell (every edge of the layer when the car is outside the grid), layer by layer
-    const int C = m.C;
-    const bool last = k == nsteps - 1;
-    if (have_info) {
-      const int cell = d_grid_cell(m, s.x, s.y);
-      const bool far = cell < 0;
-      int off[TC_MAX_LAYERS + 1];
-#pragma unroll
-      for (int l = 0; l <= TC_MAX_LAYERS; l++)
-        if (l <= C) off[l] = far ? m.edge_off[l] : m.cand_off[cell * C + l];
-#pragma unroll
-      for (int l = 0; l < TC_MAX_LAYERS; l++) {
-        if (l < C) {
-          const int lo = m.edge_off[l];
-          int bg = -1;
-          double bdg = 0;
-          int e = off[l] < off[l + 1] ? (far ? off[l] : m.cand_idx[off[l]]) : 0;
-          for (int i = off[l]; i < off[l + 1]; i++) {
-            const int en = i + 1 < off[l + 1] ? (far ? i + 1 : m.cand_idx[i + 1]) : 0;  // (the next index is on its way)
-            const double d = tc_fabs(d_dist(s.x, s.y, l_exy[4 * e], l_exy[4 * e + 1]) + d_dist(s.x, s.y, l_exy[4 * e + 2], l_exy[4 * e + 3]));
-            if (bg < 0 || d < bdg) {
-              bg = e - lo;
-              bdg = d;
-            }
-            e = en;
-          }
-          double dist_l = 0;
-          if (bg >= 0) {
-            const int ge = lo + bg;
-            const double n0x = l_exy[4 * ge], n0y = l_exy[4 * ge + 1], n1x = l_exy[4 * ge + 2], n1y = l_exy[4 * ge + 3];
-            bool certain;
-            bool inb = d_within_bounds_filter(n0x, n0y, n1x, n1y, s.x, s.y, certain);
-            if (!certain) inb = d_within_bounds(n0x, n0y, n1x, n1y, l_ofw[ge], l_orv[ge], s.x, s.y);
-            if (inb) {
-              dist_l = tc_fabs(d_distance_to_edge(n0x, n0y, n1x, n1y, s.x, s.y));
-            } else {
-              const double da = d_dist(s.x, s.y, n0x, n0y);
-              const double db = d_dist(s.front_x, s.front_y, n1x, n1y);  // FRONT axle for n1 (car.py:64)
-              dist_l = db < da ? db : da;
-            }
-          }
-          my_dist[l * TC_ENVL_NT] = dist_l;
-          if (live) {
-            if (roll.dist) roll.dist[(size_t)env * C + l] = dist_l;
-            if (roll.ne) roll.ne[(size_t)env * C + l] = bg;
-            if (last) {
-              b.laneline_distances[(size_t)env * C + l] = dist_l;
-              b.nearest_edge[(size_t)env * C + l] = bg;
-            }
-          }
-        }
-      }
-    } else {
-      for (int l = 0; l < C; l++) {  // no info this step (car.py:47-51): zero distances, no nearest edge
-        my_dist[l * TC_ENVL_NT] = 0;
-        if (live) {
-          if (roll.dist) roll.dist[(size_t)env * C + l] = 0;
-          if (roll.ne) roll.ne[(size_t)env * C + l] = -1;
-          if (last) {
-            b.laneline_distances[(size_t)env * C + l] = 0;
-            b.nearest_edge[(size_t)env * C + l] = -1;
-          }
-        }
-      }
-    }
-    // ---- reward / termination wrappers (a re-spawned env did not go through Wrapper.step)
-    if (a.n_terms > 0 && !fresh)
-      d_apply_terms_mem(a.terms, a.n_terms, my_cnt, a.car.track_width, C, cte, have_info ? s.velocity : 0.0, my_dist, reward,
-                        terminated, TC_ENVL_NT);
-    nr = (flags & TC_F_AUTORESET) ? (terminated || trunc) : 0;
-    // ---- this step's rollout rows (lane-coalesced) and pose row
-    if (live) {
-      if (roll.cte) roll.cte[env] = cte;
-      if (roll.heading_error) roll.heading_error[env] = he;
-      if (roll.truncated) roll.truncated[env] = (unsigned char)trunc;
-      if (roll.reward) roll.reward[env] = reward;
-      if (roll.terminated) roll.terminated[env] = (unsigned char)terminated;
-      if (roll.status) roll.status[env] = status;
-      if (roll.x) roll.x[env] = s.x;
-      if (roll.y) roll.y[env] = s.y;
-      if (roll.theta) roll.theta[env] = s.theta;
-      if (roll.velocity) roll.velocity[env] = s.velocity;
-      if (roll.lp_len) roll.lp_len[env] = s.lp_len;
-      if (roll.lp) {
-        int4* o = (int4*)(roll.lp + (size_t)env * 8);
-        o[0] = make_int4(s.lp[0], s.lp[1], s.lp[2], s.lp[3]);
-        o[1] = make_int4(s.lp[4], s.lp[5], s.lp[6], s.lp[7]);
-      }
-    }
-    if (sa.ma.pose_rows) {
-      FramePose fp;
-      fp.x = s.x;
-      fp.y = s.y;
-      fp.cth = have_trig ? s.cth : tc_cos(-s.theta);
-      fp.sth = have_trig ? -s.sth : tc_sin(-s.theta);
-      double pose[12];
-      cam_pose12(sa.a, env, fp, pose);
-      if (live) {
-        double2* o = (double2*)(sa.ma.pose_rows + (row0 + env) * TC_POSE_ROW);
-#pragma unroll
-        for (int i = 0; i < 6; i++) o[i] = make_double2(pose[2 * i], pose[2 * i + 1]);
-      }
-    }
-    if (sa.ma.progress && ((k + 1) % sa.ma.chunk == 0 || k + 1 == nsteps)) {
-      // end of a chunk: this workgroup's pose rows are visible device-wide, then it arrives; the last one publishes
-      __threadfence();
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const unsigned int G = sa.ma.g0 + (unsigned int)(k / sa.ma.chunk);
-        const int old = atomicAdd(sa.ma.arrive + (G & 63u), 1);
-        if (old == (int)((G >> 6) + 1u) * sa.ma.n_wg - 1)
-          __hip_atomic_store(sa.ma.progress, G + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
-  // ---- state and the last step's outputs back to the caller's buffers
-  const StepArgs& s1 = step_args();
-  const tc_buffers& b = s1.a.b;
-  if (live) {
-    b.x[env] = s.x;
-    b.y[env] = s.y;
-    b.theta[env] = s.theta;
-    b.velocity[env] = s.velocity;
-    b.steering[env] = s.steering;
-    b.radius[env] = s.radius;
-    b.front_x[env] = s.front_x;
-    b.front_y[env] = s.front_y;
-    ((int4*)b.local_path)[2 * env] = make_int4(s.lp[0], s.lp[1], s.lp[2], s.lp[3]);
-    ((int4*)b.local_path)[2 * env + 1] = make_int4(s.lp[4], s.lp[5], s.lp[6], s.lp[7]);
-    b.lp_len[env] = s.lp_len;
-    b.last_maneuver[env] = s.last_maneuver;
-    b.cte[env] = cte;
-    b.heading_error[env] = he;
-    b.reward[env] = reward;
-    b.terminated[env] = (unsigned char)terminated;
-    b.truncated[env] = (unsigned char)trunc;
-    b.status[env] = status;
-    if (b.needs_reset) b.needs_reset[env] = (unsigned char)nr;
-    if (cursor != cursor0) b.spawn_cursor[env] = cursor;
-    if (s1.a.term_counters)
-      for (int t = 0; t < s1.a.n_terms; t++) s1.a.term_counters[(size_t)env * TC_MAX_TERMS + t] = my_cnt[t * TC_ENVL_NT];
-  }
-}
-
 // One (step, env) frame per workgroup: camera stage from the pose the simulate launch left, then the raster stage.
 // Frames do not depend on each other, a launch has steps x N of them -- many more than the chip holds at once -- and
 // their cost varies 8-fold with what is in view, so the dispatcher's hand-out of the next frame to the next free slot is
@@ -3090,8 +2644,6 @@ struct FrameArgs {
   KArgs a;
   RArgs r;
   const double* pose_rows;  // [rows][N][TC_POSE_ROW]
-  int pose_row0;            // pose row of grid row 0 (the scratch-ring row of a per-chunk simulate launch, or the step index of
-                            // the call when one simulate launch covers the whole call)
 };
 // The argument block is read through a pointer the compiler cannot see through, once per stage: the stage's values are
 // then loaded (s_load from the kernarg segment) where they are used instead of all being fetched at kernel entry and
@@ -3114,7 +2666,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame
   // the pose row the simulate launch wrote for this (step, env): one address for the whole wavefront, read through the
   // scalar cache (written by an earlier launch: complete and visible before this kernel started)
   const __attribute__((address_space(4))) double* pr =
-      (const __attribute__((address_space(4))) double*)(unsigned long long)(fa.pose_rows + ((size_t)(fa.pose_row0 + blockIdx.y) * fa.a.N + env) * TC_POSE_ROW);
+      (const __attribute__((address_space(4))) double*)(unsigned long long)(fa.pose_rows + (slot0 + env) * TC_POSE_ROW);
   double pose[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) pose[i] = pr[i];
@@ -3124,13 +2676,8 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame
   TSTAMP_CLEAR();
   TSTAMP(3);
   TSTAMP_REAL(30);
-#ifdef TC_CAM_PRIO
-  __builtin_amdgcn_s_setprio(TC_CAM_PRIO);
-#endif
   cam_body<K>(fa.a, smem, env, pose, mc, false, tid, row, nseg, used, false);
-#ifdef TC_CAM_PRIO
-  __builtin_amdgcn_s_setprio(TC_RAS_PRIO);
-#endif
+
   if (nseg > fa.a.seg_lds_cap)
     __syncthreads();  // draw-list entries that went through global memory are visible to this wavefront (vmcnt(0) + barrier)
   else
@@ -3274,14 +2821,6 @@ struct tc_env {
   int frame_streams;  // short K-step calls: frame launches of consecutive chunks alternate between two streams (TC_FRAME_STREAMS)
   int prof_piped[TC_PROF_RING];
   int envg_map_lds; // tc_envg_kernel keeps the edge records in LDS when they fit (TC_ENVG_MAP_LDS=0: always from global)
-  // one simulate launch for a whole pipelined call (tc_envl_kernel + hipStreamWaitValue32 on the frame streams)
-  int persist;                 // 1 when the device supports it and TC_SIM_PERSIST != 0
-  unsigned int* progress;      // signal memory: chunks completed by the handle's simulate launches so far
-  int* arrive;                 // [64] workgroup arrival counters (device)
-  unsigned int chunk_counter;  // host copy: number of the next chunk
-  int pose_cap;                // pose rows reserved (steps of the longest call announced to tc_env_reserve_steps)
-  int env_lane;       // K-step calls: simulate with tc_envl_kernel (one lane per env) when the map's LDS copies fit (TC_ENV_LANE=0:
-                      // the 8-lanes-per-env tc_envg_kernel)
   int first_per_env;  // the first chunk of a pipelined call goes through tc_env_kernel (TC_FIRST_CHUNK_PER_ENV=0: grouped too)
   int env_grouped;  // K-step calls: simulate with tc_envg_kernel (TC_EL lanes per env); TC_ENV_GROUPED=0 keeps one wavefront per env
   // scratch ring of K-step calls (tc_env_reserve_steps): TC_RING_SLOTS chunks of ring_rows steps
@@ -3572,46 +3111,13 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   memset(e->slot_ev, 0, sizeof(e->slot_ev));
   e->last_stream = nullptr;
   e->have_call = false;
-  e->env_lane = 0;
-  if (const char* el = getenv("TC_ENV_LANE")) e->env_lane = atoi(el) != 0;
-  e->persist = 0;
-  e->progress = nullptr;
-  e->arrive = nullptr;
-  e->chunk_counter = 0;
-  e->pose_cap = 0;
-  {
-    int can = 0, dev = 0;
-    (void)hipGetDevice(&dev);
-    const bool want = !(getenv("TC_SIM_PERSIST") && atoi(getenv("TC_SIM_PERSIST")) == 0);
-    if (want && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can) {
-      void *sg = nullptr, *ar = nullptr;
-      if (hipExtMallocWithFlags(&sg, 8, hipMallocSignalMemory) == hipSuccess && hipMalloc(&ar, 64 * sizeof(int)) == hipSuccess &&
-          hipMemset(sg, 0, 8) == hipSuccess && hipMemset(ar, 0, 64 * sizeof(int)) == hipSuccess) {
-        e->progress = (unsigned int*)sg;
-        e->arrive = (int*)ar;
-        e->persist = 1;
-      } else {
-        if (sg) (void)hipFree(sg);
-        if (ar) (void)hipFree(ar);
-        (void)hipGetLastError();
-      }
-    }
-  }
   e->first_per_env = 1;
   if (const char* fp = getenv("TC_FIRST_CHUNK_PER_ENV")) e->first_per_env = atoi(fp) != 0;
   e->frame_streams = 2;
   if (const char* fsn = getenv("TC_FRAME_STREAMS")) e->frame_streams = atoi(fsn) == 1 ? 1 : 2;
   memset(e->prof_piped, 0, sizeof(e->prof_piped));
-  // The frame streams get the LOWEST queue priority: when a simulate workgroup of the next chunk (caller's stream) and the
-  // thousands of queued frame workgroups compete for the LDS / wave slots a finishing workgroup frees, the simulate
-  // launch must win -- it is the latency chain everything else waits for, and a workgroup that needs several frame
-  // workgroups' worth of LDS on ONE CU otherwise starves until the frame launch drains (measured with the lane-per-env
-  // kernel, 59 KB per workgroup: 550 us before its first step ran).  TC_FRAME_PRIO=0 keeps the default priority.
-  int prio_least = 0, prio_greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  if (getenv("TC_FRAME_PRIO") && atoi(getenv("TC_FRAME_PRIO")) == 0) prio_least = 0;
-  if (hipStreamCreateWithPriority(&e->frame_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
-      hipStreamCreateWithPriority(&e->frame_stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&e->frame_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->frame_stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->frames_ev2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->sim_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->frames_ev, hipEventDisableTiming) != hipSuccess ||
@@ -3772,6 +3278,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
 #ifdef TC_EXPERIMENT
     // occupancy experiments (make dev-exp, never shipped): unused LDS bytes per frame workgroup -> fewer workgroups per CU
     if (const char* pd = getenv("TC_LDS_PAD")) e->frame_lds += atoi(pd);
+    if (const char* pd = getenv("TC_STEP_LDS_PAD")) e->step_lds += atoi(pd);
 #endif
   }
   if (L.total > 160 * 1024 || e->r_lds > 160 * 1024) {
@@ -3794,9 +3301,6 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
         }
     }
   }
-  if (envl_lds_bytes(m) > 150 * 1024) e->env_lane = 0;  // (a map whose LDS copies do not fit one workgroup: 8 lanes per env)
-  if (e->env_lane && envl_lds_bytes(m) > 40 * 1024)
-    (void)hipFuncSetAttribute((const void*)tc_envl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)envl_lds_bytes(m));
   {  // tc_envg_kernel's LDS copies of the map (edge records + fat lanepath nodes, see launch()) can exceed the 48 KB default
     const size_t envg_lds = ((size_t)m.total_edges * 48 + 15) / 16 * 16 + (size_t)m.lpN * sizeof(LpNode);
     if (envg_lds > 40 * 1024)
@@ -3890,8 +3394,6 @@ extern "C" int tc_env_destroy(tc_env* e) {
   if (e && e->segm_g) (void)hipFree(e->segm_g);
   if (e && e->segm_n) (void)hipFree(e->segm_n);
   if (e && e->pose_rows) (void)hipFree(e->pose_rows);
-  if (e && e->progress) (void)hipFree(e->progress);
-  if (e && e->arrive) (void)hipFree(e->arrive);
   if (e && e->k.seg_g) (void)hipFree(e->k.seg_g);
   if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
   if (e && e->k.terms) (void)hipFree((void*)e->k.terms);
@@ -4246,10 +3748,7 @@ extern "C" int tc_env_reserve_steps(tc_env* e, int32_t max_chunk_steps) {
   if (!e || max_chunk_steps < 1) return TC_E_INVALID;
   int rows = max_chunk_steps < e->chunk ? max_chunk_steps : e->chunk;
   if (rows < 2) rows = 2;  // (a pipelined call never uses chunks of fewer than 2 steps)
-  // pose rows: one per (step, env) of the longest call announced -- with one simulate launch per call the simulate
-  // kernel runs ahead of the frame launches by as many chunks as it likes (128 bytes per row: 64 MB for 128 x 4096)
-  const int pose_want = max_chunk_steps > TC_RING_SLOTS * rows ? max_chunk_steps : TC_RING_SLOTS * rows;
-  if (e->ring_rows >= rows && e->pose_cap >= pose_want) return TC_OK;
+  if (e->ring_rows >= rows) return TC_OK;
   HIP_TRY(hipDeviceSynchronize());  // earlier launches may still read the old ring
   if (e->segm_g) (void)hipFree(e->segm_g);
   if (e->segm_n) (void)hipFree(e->segm_n);
@@ -4257,12 +3756,11 @@ extern "C" int tc_env_reserve_steps(tc_env* e, int32_t max_chunk_steps) {
   e->segm_g = e->segm_n = nullptr;
   e->pose_rows = nullptr;
   e->ring_rows = 0;
-  e->pose_cap = 0;
   const size_t R = (size_t)TC_RING_SLOTS * rows * e->k.N;
   void *p = nullptr, *q = nullptr, *pr = nullptr;
   hipError_t he = hipMalloc(&p, R * e->k.seg_cap * 5 * sizeof(int));
   if (he == hipSuccess) he = hipMalloc(&q, R * sizeof(int));
-  if (he == hipSuccess) he = hipMalloc(&pr, (size_t)pose_want * e->k.N * TC_POSE_ROW * sizeof(double));
+  if (he == hipSuccess) he = hipMalloc(&pr, R * TC_POSE_ROW * sizeof(double));
   if (he != hipSuccess) {
     if (p) (void)hipFree(p);
     if (q) (void)hipFree(q);
@@ -4273,7 +3771,6 @@ extern "C" int tc_env_reserve_steps(tc_env* e, int32_t max_chunk_steps) {
   e->segm_n = (int*)q;
   e->pose_rows = (double*)pr;
   e->ring_rows = rows;
-  e->pose_cap = pose_want;
   return TC_OK;
 }
 
@@ -4347,20 +3844,6 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     // 66.2 -> 58.3 us per step, 20-step call 46.9 -> 44.0; with chunks of 10 steps it costs 7 %, so longer calls keep one
     // stream and their frame launches follow one another, as a kernel trace of the default command shows them).
     const bool two_fs = piped && e->frame_streams == 2 && chunk < 8;
-    // ONE simulate launch for the whole call (tc_envl_kernel, one lane per env), the frame launches of chunk c gated on
-    // their stream by the chunk counter that launch publishes (hipStreamWaitValue32) instead of by an event behind a
-    // per-chunk simulate launch.  Why: a simulate launch that has to find room on a chip the frame kernel keeps 100 %
-    // full (all 160 KB of LDS on every CU) waits until the frame launch in front of it drains -- measured: the
-    // lane-per-env kernel needed ~550 us before its first step, per chunk.  Launched once, at the start of the call,
-    // it is resident before the first frame exists, runs ahead of the frames by as many chunks as it likes (the pose
-    // rows of the whole call are kept) and never competes for a slot again.  Not while the stream is being captured
-    // into a graph (a value wait cannot be captured): then, and for calls longer than the pose rows reserved, the
-    // per-chunk form below runs.
-    bool persist = piped && e->persist && nsteps <= e->pose_cap;
-    if (persist) {
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) persist = false;
-    }
     const size_t esz = cdtype == TC_F32 ? 4 : 8;
     const bool thick = e->k.cam.thickness > 1, cls = e->k.cam.format == TC_FMT_CLASSES;
     (void)thick;
@@ -4370,87 +3853,11 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     e->draw_n = 0;
     const int C = e->k.m.C;
     int ci = 0;
-    const unsigned int g0 = e->chunk_counter;
-    if (persist) {
-      // the frame streams start behind everything already on the caller's stream (an earlier reader of the rollout buffers)
-      HIP_TRY(hipEventRecord(e->sim_ev, main));
-      HIP_TRY(hipStreamWaitEvent(e->frame_stream, e->sim_ev, 0));
-      if (two_fs) HIP_TRY(hipStreamWaitEvent(e->frame_stream2, e->sim_ev, 0));
-      StepArgs sa;
-      memset(&sa, 0, sizeof(sa));
-      sa.a = e->k;
-      sa.a.env0 = 0;
-      sa.a.seg_g = e->segm_g;
-      sa.a.seg_n = e->segm_n;
-      sa.ma = ma;  // (nsteps, rollout rows of the whole call)
-      sa.ma.seg_rows = 2;
-      sa.ma.cam_here = 0;
-      sa.ma.pose_rows = e->pose_rows;
-      sa.ma.chunk = chunk;
-      sa.ma.progress = e->progress;
-      sa.ma.arrive = e->arrive;
-      sa.ma.g0 = g0;
-      sa.mode = mode;
-      sa.cdtype = cdtype;
-      sa.flags = flags;
-      sa.car_control = cc;
-      sa.maneuver = man;
-      sa.spawn_nodes = spawn;
-      sa.mask = mask;
-      if (e->env_lane) {
-        sa.ma.n_wg = (N + TC_ENVL_NT - 1) / TC_ENVL_NT;
-        hipLaunchKernelGGL(tc_envl_kernel, dim3(sa.ma.n_wg), dim3(TC_ENVL_NT), envl_lds_bytes(e->k.m), main, sa);
-      } else {
-        const size_t map_bytes = ((size_t)e->k.m.total_edges * 48 + 15) / 16 * 16, fat_bytes = (size_t)e->k.m.lpN * sizeof(LpNode);
-        sa.ma.map_lds = (e->envg_map_lds && map_bytes <= 40 * 1024) ? 1 : 0;
-        sa.ma.fat_lds = (e->envg_map_lds && fat_bytes <= 56 * 1024) ? 1 : 0;
-        sa.ma.n_wg = (N + TC_ENVG_NT / TC_EL - 1) / (TC_ENVG_NT / TC_EL);
-        hipLaunchKernelGGL(tc_envg_kernel, dim3(sa.ma.n_wg), dim3(TC_ENVG_NT),
-                           (sa.ma.map_lds ? map_bytes : 0) + (sa.ma.fat_lds ? fat_bytes : 0), main, sa);
-      }
-      HIP_TRY(hipGetLastError());
-      if (prof) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
-      e->chunk_counter += (unsigned int)((nsteps + chunk - 1) / chunk);
-    }
     for (int c0 = 0, cn = 0; c0 < nsteps; c0 += cn, ci++) {
       cn = nsteps - c0 < chunk ? nsteps - c0 : chunk;
       const size_t r0 = (size_t)c0 * N;                 // first [step][env] row of this chunk in the caller's arrays
       const int rslot = ci % TC_RING_SLOTS;
       const size_t rb = (size_t)rslot * e->ring_rows;   // first row of this chunk in the scratch ring
-      if (persist) {
-        // frames of chunk ci: behind the chunk counter on their stream, and behind the frames that used this ring slot
-        // (draw-list overflow, list lengths) three chunks ago when those ran on the other stream
-        if (two_fs) fs = (ci & 1) ? e->frame_stream2 : e->frame_stream;
-        HIP_TRY(hipStreamWaitValue32(fs, e->progress, g0 + (unsigned int)ci + 1u, hipStreamWaitValueGte, 0xffffffffu));
-        if (two_fs && ci >= TC_RING_SLOTS) HIP_TRY(hipStreamWaitEvent(fs, e->slot_ev[rslot], 0));
-        used_fs[fs == e->frame_stream2 ? 1 : 0] = true;
-        if (prof && first_frames) HIP_TRY(hipEventRecord(e->ev[3][slot], fs));
-        first_frames = false;
-        RArgs r = make_rargs(e, e->segm_g, e->segm_n, e->k.seg_cap, nullptr, flags, 0, roll->obs + r0 * (size_t)e->obs_bytes, mode == MODE_STEP);
-        r.seg_row0 = (int)rb;
-        r.noise_row0 = c0;
-        r.obs_row_stride = (long long)N * (long long)e->obs_bytes;
-        FrameArgs fa;
-        memset(&fa, 0, sizeof(fa));
-        fa.a = e->k;
-        fa.a.dbg = flags;
-        fa.a.env0 = 0;
-        fa.a.seg_g = e->segm_g;
-        fa.a.seg_n = e->segm_n;
-        fa.r = r;
-        fa.pose_rows = e->pose_rows;
-        fa.pose_row0 = c0;
-        frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
-        fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
-        fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->seg_lds_cap;
-        hipLaunchKernelGGL(fk, dim3(N, cn), dim3(TC_NT), e->frame_lds, fs, fa);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e->slot_ev[rslot], fs));
-        const int w = e->draw_n < TC_RING_SLOTS ? e->draw_n++ : (memmove(e->draw_rows[0], e->draw_rows[1], sizeof(int) * 2 * (TC_RING_SLOTS - 1)), TC_RING_SLOTS - 1);
-        e->draw_rows[w][0] = (int)rb;
-        e->draw_rows[w][1] = cn;
-        continue;
-      }
       // the frames that read this ring slot TC_RING_SLOTS chunks ago must be done before it is rewritten
       if (piped && ci >= TC_RING_SLOTS) HIP_TRY(hipStreamWaitEvent(main, e->slot_ev[rslot], 0));
       StepArgs sa;
@@ -4493,11 +3900,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       // the one-wavefront-per-env kernel (4096 wavefronts, bound by throughput: ~15 us per step) instead of the grouped
       // one (512 wavefronts, a latency chain: 13-23 us per step).  20-step call 48.4 -> 47.2 us per step, 128-step calls
       // 38.2 -> 37.6.  Both kernels read and leave the env's state in the caller's buffers, bit for bit the same.
-      if (frames && e->env_grouped && e->env_lane && !piped) {
-        // one lane per env, a launch per chunk: only where nothing competes for the chip (chunks that follow each other on
-        // the caller's stream); beside a frame launch it is the single launch per call above or the 8-lane kernel below
-        hipLaunchKernelGGL(tc_envl_kernel, dim3((N + TC_ENVL_NT - 1) / TC_ENVL_NT), dim3(TC_ENVL_NT), envl_lds_bytes(e->k.m), main, sa);
-      } else if (frames && e->env_grouped && !(e->first_per_env && c0 == 0 && piped && nsteps > chunk)) {  // (a one-chunk call: grouped)
+      if (frames && e->env_grouped && !(e->first_per_env && c0 == 0 && piped && nsteps > chunk)) {  // (a one-chunk call: grouped)
         // LDS copies of the lane-line edge records (48 B per edge) and of the lanepath's fat node records (96 B per node):
         // simple_layout 12.4 + 17.5 KB, knuffingen 34.6 + 40.2 KB per workgroup of 32 envs (a CU holds one or two such
         // workgroups: 128 of them cover 4096 envs)
@@ -4538,7 +3941,6 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         fa.a.seg_n = e->segm_n;
         fa.r = r;
         fa.pose_rows = e->pose_rows;
-        fa.pose_row0 = r.seg_row0;  // (a per-chunk simulate launch wrote this chunk's pose rows at its ring rows)
         frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
         fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
         fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->seg_lds_cap;
@@ -4730,9 +4132,7 @@ extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t n_ste
   if (name && name_cap > 0)
     snprintf(name, (size_t)name_cap, "%s",
              f ? "tc_step_kernel"
-               : frames ? (e->env_grouped ? ((e->env_lane && (!e->pipe || (e->persist && (e->pose_cap == 0 || n_steps <= e->pose_cap))))
-                                                 ? "tc_envl_kernel+tc_frame_kernel" : "tc_envg_kernel+tc_frame_kernel")
-                                          : "tc_env_kernel+tc_frame_kernel")
+               : frames ? (e->env_grouped ? "tc_envg_kernel+tc_frame_kernel" : "tc_env_kernel+tc_frame_kernel")
                : do_raster ? "tc_env_kernel+tc_raster_kernel"
                            : "tc_env_kernel");
   return TC_OK;

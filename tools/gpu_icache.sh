@@ -13,7 +13,7 @@ ch = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for p in glob.glob(f"/tmp/ic_{ch}/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(p)):
-        k = "frame" if "tc_frame_kernel" in r["Kernel_Name"] else "sim" if ("tc_envg" in r["Kernel_Name"] or "tc_envl" in r["Kernel_Name"]) else None
+        k = "frame" if "tc_frame_kernel" in r["Kernel_Name"] else "sim" if ("tc_envg" in r["Kernel_Name"]) else None
         if k: agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, d in agg.items():
     print(f"TC_CHUNK={ch} {k}: " + "  ".join(f"{c}={v:.3g}" for c, v in sorted(d.items())), " miss rate %.3f" % (d["SQC_ICACHE_MISSES"] / max(d["SQC_ICACHE_REQ"], 1)))

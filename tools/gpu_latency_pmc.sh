@@ -19,7 +19,7 @@ ch = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for p in glob.glob(f"/tmp/lp_{ch}_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(p)):
-        k = "frame" if "tc_frame_kernel" in r["Kernel_Name"] else "sim" if ("tc_envg" in r["Kernel_Name"] or "tc_envl" in r["Kernel_Name"]) else None
+        k = "frame" if "tc_frame_kernel" in r["Kernel_Name"] else "sim" if ("tc_envg" in r["Kernel_Name"]) else None
         if k: agg[k][r["Counter_Name"]] = agg[k][r["Counter_Name"]] + float(r["Counter_Value"])
 for k, d in sorted(agg.items()):
     w = max(d.get("SQ_WAVES", 0) / 4, 1)   # SQ_WAVES was collected in 4 of the passes... per pass value: each pass sums all dispatches

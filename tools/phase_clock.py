@@ -32,7 +32,7 @@ NAMES = ["entry -> tracking done (phase A)", "state / info write-back", "lane-li
 SUB = [("A: state from LDS, action, kinematics", 0, 23), ("A: lanepath tracking (dependent fat-node loads)", 23, 1),
        ("B: node distances + sync", 2, 14), ("B: 5 x (edge scan + wave argmin)", 14, 15), ("B: per-layer tail (loads, bounds, distance)", 15, 16),
        ("clip pass 1 (behind -> front)", 4, 17), ("clip pass 2", 17, 18), ("range flags + clip pass 3", 18, 19), ("clip pass 4", 19, 5),
-       ("setup: table offsets, segment fetch", 9, 20), ("  .. probe 9 -> a second probe right behind it", 9, 26), ("  .. -> (experiment) re-read right behind it", 26, 23), ("  .. -> its second value", 23, 28), ("  .. -> the loop's own re-read arrived", 28, 27), ("  .. -> second argument (same line)", 27, 24), ("  .. to the per-segment branch", 24, 25),
+       ("setup: table offsets, segment fetch", 9, 20), ("  .. probe 9 -> a second probe right behind it", 9, 26), ("  .. -> first instructions of the set-up (bimodal: issue contention)", 26, 27), ("  .. -> second argument (same line)", 27, 24), ("  .. to the per-segment branch", 24, 25),
        ("  .. draw-list entry from LDS", 25, 20), ("setup: ThickLine quad (sqrt, div, rounding)", 20, 21),
        ("setup: fill events", 21, 22), ("setup: table writes + sync", 22, 10)]
 

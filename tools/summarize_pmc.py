@@ -10,7 +10,7 @@ a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles", a.round)
 os.makedirs(out, exist_ok=True)
-KINDS = ("tc_frame_kernel", "tc_step_kernel", "tc_raster_kernel", "tc_envl_kernel", "tc_envg_kernel", "tc_env_kernel", "tc_noise_kernel")
+KINDS = ("tc_frame_kernel", "tc_step_kernel", "tc_raster_kernel", "tc_envg_kernel", "tc_env_kernel", "tc_noise_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 grid = {}
 for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{a.tag}", "p*", "*", "*_counter_collection.csv")):
