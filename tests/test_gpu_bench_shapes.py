@@ -240,3 +240,28 @@ def test_first_step_multi_call_can_be_captured_into_a_graph():
         assert torch.equal(a.state[k], b.state[k]), k
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("order,n", [("1", 4096), ("3", 2048), ("0", 2048)])
+def test_single_steps_with_cost_aware_env_order(order, n, monkeypatch):
+    """tc_step deals the envs to its workgroups by the previous frames' draw-list lengths (tc_order_kernel: which envs
+    share a SIMD is fixed by the workgroup index).  Any permutation must give the oracle's results for
+    every env: 20 closed-loop steps with the order refreshed every step / every third step / never, autoreset on --
+    a workgroup index mapped to the wrong env, or an env left out, shows as a state that did not advance."""
+    monkeypatch.setenv("TC_STEP_ORDER", order)
+    env = make_env("simple_layout", "r64", "classes", n, autoreset=True, spawn_queue_len=8)
+    env.reset(seed=4)
+    o = make_oracle(env, threads=16)
+    o.reset(env._keep[0].cpu().numpy())
+    o.spawn_queue = env._aux["spawn_queue"].cpu().numpy()
+    cc, man = mixed_actions(n, 20, seed=8)
+    cc_h, man_h = cc.cpu().numpy().astype(np.float64), man.cpu().numpy()
+    for k in range(20):
+        env.step_device(cc[k], man[k])
+        o.step(cc_h[k], man_h[k], flags=orc.F_AUTORESET)
+        if k % 5 == 4:
+            assert_same(env, o, env.n_classes, label=f"order={order} step {k}")
+    assert_same(env, o, env.n_classes, label=f"order={order} end")
+    stats = env.draw_list_stats()
+    assert stats["frames"] == n and stats["max_segments"] > 0
+    env.close()

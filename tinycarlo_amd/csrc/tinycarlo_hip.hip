@@ -249,6 +249,7 @@ struct RollStep {
   int* ne;       // [N][C]
   int* lp;       // [N][8]
   int* lp_len;
+  size_t row0;   // first row of the step in the [K][N] arrays above (k * N)
 };
 
 struct KArgs {
@@ -1006,21 +1007,21 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
       lv->he = he;
       lv->trunc = trunc;
       lv->status = status;
-      if (roll.cte) roll.cte[env] = cte;
-      if (roll.heading_error) roll.heading_error[env] = he;
-      if (roll.truncated) roll.truncated[env] = (unsigned char)trunc;
-      if (roll.status) roll.status[env] = status;
-      if (roll.x) roll.x[env] = s.x;
-      if (roll.y) roll.y[env] = s.y;
-      if (roll.theta) roll.theta[env] = s.theta;
-      if (roll.velocity) roll.velocity[env] = s.velocity;
-      if (roll.lp_len) roll.lp_len[env] = s.lp_len;
+      if (roll.cte) roll.cte[roll.row0 + env] = cte;
+      if (roll.heading_error) roll.heading_error[roll.row0 + env] = he;
+      if (roll.truncated) roll.truncated[roll.row0 + env] = (unsigned char)trunc;
+      if (roll.status) roll.status[roll.row0 + env] = status;
+      if (roll.x) roll.x[roll.row0 + env] = s.x;
+      if (roll.y) roll.y[roll.row0 + env] = s.y;
+      if (roll.theta) roll.theta[roll.row0 + env] = s.theta;
+      if (roll.velocity) roll.velocity[roll.row0 + env] = s.velocity;
+      if (roll.lp_len) roll.lp_len[roll.row0 + env] = s.lp_len;
       if (!late) {
         lv->reward = reward;
         lv->terminated = terminated;
         lv->needs_reset = (flags & TC_F_AUTORESET) ? (terminated || trunc) : 0;
-        if (roll.reward) roll.reward[env] = reward;
-        if (roll.terminated) roll.terminated[env] = (unsigned char)terminated;
+        if (roll.reward) roll.reward[roll.row0 + env] = reward;
+        if (roll.terminated) roll.terminated[roll.row0 + env] = (unsigned char)terminated;
       }
     }
     if (tid < 8) {  // register-resident select (a runtime-indexed s.lp[tid] would live in scratch)
@@ -1028,7 +1029,7 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
 #pragma unroll
       for (int i = 1; i < 8; i++) v = tid == i ? s.lp[i] : v;
       lv->lp[tid] = v;
-      if (roll.lp) roll.lp[(size_t)env * 8 + tid] = v;
+      if (roll.lp) roll.lp[(roll.row0 + env) * 8 + tid] = v;
     }
 
     TSTAMP(2);
@@ -1150,16 +1151,16 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
         }
         lv->dist[l] = dist_l;
         lv->ne[l] = my_e;
-        if (roll.dist) roll.dist[(size_t)env * C + l] = dist_l;
-        if (roll.ne) roll.ne[(size_t)env * C + l] = my_e;
+        if (roll.dist) roll.dist[(roll.row0 + env) * C + l] = dist_l;
+        if (roll.ne) roll.ne[(roll.row0 + env) * C + l] = my_e;
       }
       TSTAMP(16);
       lds_sync();  // dn aliases the camera's node buffer
     } else if (tid < C) {
       lv->dist[tid] = 0;
       lv->ne[tid] = -1;
-      if (roll.dist) roll.dist[(size_t)env * C + tid] = 0;
-      if (roll.ne) roll.ne[(size_t)env * C + tid] = -1;
+      if (roll.dist) roll.dist[(roll.row0 + env) * C + tid] = 0;
+      if (roll.ne) roll.ne[(roll.row0 + env) * C + tid] = -1;
     }
     if (late) {
       // a re-spawned env did not go through Wrapper.step (the reference's reset() bypasses the wrappers)
@@ -1172,8 +1173,8 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
         lv->reward = reward;
         lv->terminated = terminated;
         lv->needs_reset = (flags & TC_F_AUTORESET) ? (terminated || trunc) : 0;
-        if (roll.reward) roll.reward[env] = reward;
-        if (roll.terminated) roll.terminated[env] = (unsigned char)terminated;
+        if (roll.reward) roll.reward[roll.row0 + env] = reward;
+        if (roll.terminated) roll.terminated[roll.row0 + env] = (unsigned char)terminated;
       }
     }
   }
@@ -1401,22 +1402,25 @@ struct MultiArgs {
                       // edge records (or at offset 0 without them), and lanepath tracking reads them there
   tc_rollout roll;
 };
+// (base pointers and the row: the address of a row is formed where it is stored, under its null test -- forming all 15 row
+// pointers at the top of every step was ~60 scalar instructions per step of every wavefront, 4 % of cfg2)
 __device__ __forceinline__ RollStep roll_at(const tc_rollout& r, size_t row0, int C) {
   RollStep q;
-  q.reward = r.reward ? r.reward + row0 : nullptr;
-  q.cte = r.cte ? r.cte + row0 : nullptr;
-  q.heading_error = r.heading_error ? r.heading_error + row0 : nullptr;
-  q.terminated = r.terminated ? r.terminated + row0 : nullptr;
-  q.truncated = r.truncated ? r.truncated + row0 : nullptr;
-  q.status = r.status ? r.status + row0 : nullptr;
-  q.x = r.x ? r.x + row0 : nullptr;
-  q.y = r.y ? r.y + row0 : nullptr;
-  q.theta = r.theta ? r.theta + row0 : nullptr;
-  q.velocity = r.velocity ? r.velocity + row0 : nullptr;
-  q.dist = r.laneline_distances ? r.laneline_distances + row0 * C : nullptr;
-  q.ne = r.nearest_edge ? r.nearest_edge + row0 * C : nullptr;
-  q.lp = r.local_path ? r.local_path + row0 * 8 : nullptr;
-  q.lp_len = r.lp_len ? r.lp_len + row0 : nullptr;
+  q.reward = r.reward;
+  q.cte = r.cte;
+  q.heading_error = r.heading_error;
+  q.terminated = r.terminated;
+  q.truncated = r.truncated;
+  q.status = r.status;
+  q.x = r.x;
+  q.y = r.y;
+  q.theta = r.theta;
+  q.velocity = r.velocity;
+  q.dist = r.laneline_distances;
+  q.ne = r.nearest_edge;
+  q.lp = r.local_path;
+  q.lp_len = r.lp_len;
+  q.row0 = row0;
   return q;
 }
 
@@ -2177,6 +2181,7 @@ struct StepArgs {
   const int* maneuver;
   const int* spawn_nodes;
   const unsigned char* mask;
+  const int* env_order;  // tc_step_kernel: workgroup w works on env env_order[w] (a permutation of 0..N-1), or NULL = env w
 };
 
 // The launch arguments, read through a pointer the optimiser cannot see through.  Inside the step loop of tc_step_multi
@@ -2568,8 +2573,8 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
           }
           gl.dist[l] = dist_l;
           if (live) {
-            if (roll.dist) roll.dist[(size_t)env * C + l] = dist_l;
-            if (roll.ne) roll.ne[(size_t)env * C + l] = ne;
+            if (roll.dist) roll.dist[(roll.row0 + env) * C + l] = dist_l;
+            if (roll.ne) roll.ne[(roll.row0 + env) * C + l] = ne;
           }
           if (last && live) {
             b.laneline_distances[(size_t)env * C + l] = dist_l;
@@ -2582,8 +2587,8 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
       for (int l = sub; l < C; l += TC_EL) {  // no info this step (car.py:47-51): zero distances, no nearest edge
         gl.dist[l] = 0;
         if (live) {
-          if (roll.dist) roll.dist[(size_t)env * C + l] = 0;
-          if (roll.ne) roll.ne[(size_t)env * C + l] = -1;
+          if (roll.dist) roll.dist[(roll.row0 + env) * C + l] = 0;
+          if (roll.ne) roll.ne[(roll.row0 + env) * C + l] = -1;
         }
         if (last && live) {
           b.laneline_distances[(size_t)env * C + l] = 0;
@@ -2599,19 +2604,19 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
     nr = (flags & TC_F_AUTORESET) ? (terminated || trunc) : 0;
     // ---- this step's rollout rows and pose row
     if (live && sub == 0) {
-      if (roll.cte) roll.cte[env] = cte;
-      if (roll.heading_error) roll.heading_error[env] = he;
-      if (roll.truncated) roll.truncated[env] = (unsigned char)trunc;
-      if (roll.reward) roll.reward[env] = reward;
-      if (roll.terminated) roll.terminated[env] = (unsigned char)terminated;
-      if (roll.status) roll.status[env] = status;
-      if (roll.x) roll.x[env] = s.x;
-      if (roll.y) roll.y[env] = s.y;
-      if (roll.theta) roll.theta[env] = s.theta;
-      if (roll.velocity) roll.velocity[env] = s.velocity;
-      if (roll.lp_len) roll.lp_len[env] = s.lp_len;
+      if (roll.cte) roll.cte[roll.row0 + env] = cte;
+      if (roll.heading_error) roll.heading_error[roll.row0 + env] = he;
+      if (roll.truncated) roll.truncated[roll.row0 + env] = (unsigned char)trunc;
+      if (roll.reward) roll.reward[roll.row0 + env] = reward;
+      if (roll.terminated) roll.terminated[roll.row0 + env] = (unsigned char)terminated;
+      if (roll.status) roll.status[roll.row0 + env] = status;
+      if (roll.x) roll.x[roll.row0 + env] = s.x;
+      if (roll.y) roll.y[roll.row0 + env] = s.y;
+      if (roll.theta) roll.theta[roll.row0 + env] = s.theta;
+      if (roll.velocity) roll.velocity[roll.row0 + env] = s.velocity;
+      if (roll.lp_len) roll.lp_len[roll.row0 + env] = s.lp_len;
       if (roll.lp) {
-        int4* o = (int4*)(roll.lp + (size_t)env * 8);
+        int4* o = (int4*)(roll.lp + (roll.row0 + env) * 8);
         o[0] = make_int4(s.lp[0], s.lp[1], s.lp[2], s.lp[3]);
         o[1] = make_int4(s.lp[4], s.lp[5], s.lp[6], s.lp[7]);
       }
@@ -2722,8 +2727,10 @@ template <int K, bool THICK, int FMT>
 __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_kernel(StepArgs sa_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   const StepArgs& s0 = step_args();
-  const int env = s0.a.env0 + blockIdx.x;
-  if (env >= s0.a.N) return;
+  if ((int)blockIdx.x >= s0.a.N) return;
+  // which env this workgroup works on: see tc_order_kernel (a scalar load: one address for the whole wavefront)
+  const int env = s0.env_order ? uni_i(((const __attribute__((address_space(4))) int*)(unsigned long long)s0.env_order)[blockIdx.x])
+                               : s0.a.env0 + (int)blockIdx.x;
   if (s0.mode == MODE_RESET && s0.mask && !s0.mask[env]) return;  // whole workgroup skips
   live_in(s0.a, smem, env, s0.mode, s0.flags);
   const int nsteps = s0.ma.nsteps;
@@ -2765,6 +2772,48 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
   TSTAMP_END(t_prev);
   const StepArgs& s1 = step_args();
   if (s1.mode != MODE_RENDER) live_out(s1.a, smem, env);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Which env each workgroup of a single-step launch works on.  One tc_step is N one-wavefront workgroups, exactly one
+// resident round on the chip, so it lasts as long as its busiest SIMD -- and the hardware puts workgroups w, w + G,
+// w + 2G, ... (G = number of SIMDs: 1024) on the SAME SIMD, whichever SIMD that is in a given launch (measured,
+// tools/hw_map.py: every SIMD holds env ids that differ by exactly 1024; sum of the four wavefront lives per SIMD:
+// busiest / mean = 1.4-1.6, because an env's frame costs between ~10 k and ~130 k clocks and keeps its kind of view for
+// many steps).  The cost of a frame is known well enough from the frame before it (its draw-list length; the wavefront's
+// measured life as the key was tried and is worse than no re-deal at all: it carries the contention of the previous deal), so the envs are
+// sorted by that and dealt to the G groups in serpentine order -- heaviest with lightest -- and workgroup w takes env
+// order[w].  Any permutation gives the same results (envs are independent); only the launch time changes.
+// One workgroup: counting sort of the N lengths (descending), then rank r -> workgroup (r / G) * G + (r / G even ? r % G :
+// G - 1 - r % G).
+#define TC_ORDER_NT 1024
+#define TC_ORDER_BINS 256
+__global__ __launch_bounds__(TC_ORDER_NT) void tc_order_kernel(const int* cost, int N, int G, int* order) {
+  __shared__ int hist[TC_ORDER_BINS], cursor[TC_ORDER_BINS];
+  const int t = threadIdx.x;
+  for (int b = t; b < TC_ORDER_BINS; b += TC_ORDER_NT) hist[b] = 0;
+  __syncthreads();
+  for (int i = t; i < N; i += TC_ORDER_NT) {
+    int c = cost[i];
+    c = c < 0 ? 0 : (c > TC_ORDER_BINS - 1 ? TC_ORDER_BINS - 1 : c);
+    atomicAdd(&hist[TC_ORDER_BINS - 1 - c], 1);  // bin 0 = the heaviest
+  }
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int b = 0; b < TC_ORDER_BINS; b++) {
+      cursor[b] = acc;
+      acc += hist[b];
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < N; i += TC_ORDER_NT) {
+    int c = cost[i];
+    c = c < 0 ? 0 : (c > TC_ORDER_BINS - 1 ? TC_ORDER_BINS - 1 : c);
+    const int r = atomicAdd(&cursor[TC_ORDER_BINS - 1 - c], 1);  // rank among the envs, heaviest first
+    const int row = r / G, j = r - row * G;
+    order[row * G + ((row & 1) ? G - 1 - j : j)] = i;
+  }
 }
 
 typedef void (*fused_kern_t)(StepArgs);
@@ -2842,6 +2891,10 @@ struct tc_env {
   int draw_rows[TC_RING_SLOTS][2];
   int draw_n;
   int step_lds;  // tc_step_kernel: LDS bytes per workgroup (lds.total grown like frame_lds)
+  // cost-aware env order of single-step launches (tc_order_kernel): refreshed every order_every-th tc_step
+  int* env_order;   // [N] device, a permutation (identity until the first refresh); NULL = off (TC_STEP_ORDER=0, N % G != 0)
+  int order_g;      // G = SIMDs of the device
+  int order_every, order_calls;
   int seg_lds_limit;  // TC_SEG_LDS_CAP
   int frame_lds, seg_lds_off, seg_lds_cap;  // tc_frame_kernel: LDS bytes per workgroup, draw-list region (see KArgs)
   int frame_streams;  // short K-step calls: frame launches of consecutive chunks alternate between two streams (TC_FRAME_STREAMS)
@@ -3368,6 +3421,31 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
     e->k.seg_g = (int*)p;
     e->k.seg_n = (int*)q;
   }
+  {
+    // cost-aware env order of single-step launches (tc_order_kernel): when the N workgroups are whole rows of G = SIMDs
+    // of the device and all resident at once (N / G <= 4 wavefronts per SIMD).  TC_STEP_ORDER=n refreshes the order every
+    // n-th tc_step (default 8), 0 switches it off.
+    e->env_order = nullptr;
+    e->order_calls = 0;
+    e->order_every = 8;
+    if (const char* so = getenv("TC_STEP_ORDER")) e->order_every = atoi(so) > 0 ? atoi(so) : 0;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    e->order_g = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) e->order_g = prop.multiProcessorCount * 4;
+    if (e->order_every > 0 && e->order_g > 0 && num_envs % e->order_g == 0 && num_envs / e->order_g <= 4 && num_envs / e->order_g >= 2) {
+      std::vector<int> ident((size_t)num_envs);
+      for (int i = 0; i < num_envs; i++) ident[(size_t)i] = i;
+      void* o = nullptr;
+      if (hipMalloc(&o, (size_t)num_envs * sizeof(int)) == hipSuccess &&
+          hipMemcpy(o, ident.data(), (size_t)num_envs * sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
+        e->env_order = (int*)o;
+      } else {
+        if (o) (void)hipFree(o);
+        (void)hipGetLastError();
+      }
+    }
+  }
   *out = e;
   return TC_OK;
 }
@@ -3422,6 +3500,7 @@ extern "C" int tc_env_destroy(tc_env* e) {
   if (e && e->pose_rows) (void)hipFree(e->pose_rows);
   if (e && e->k.seg_g) (void)hipFree(e->k.seg_g);
   if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
+  if (e && e->env_order) (void)hipFree(e->env_order);
   if (e && e->k.terms) (void)hipFree((void*)e->k.terms);
   if (e && e->k.spawn_tab) (void)hipFree((void*)e->k.spawn_tab);
   if (e && e->noise_hw) (void)hipFree(e->noise_hw);
@@ -4037,6 +4116,15 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     sa.maneuver = man;
     sa.spawn_nodes = spawn;
     sa.mask = mask;
+    if (e->env_order && nsteps == 1) {
+      // every order_every-th step the envs are re-dealt to the workgroups by the draw-list lengths of the step before
+      // (tc_order_kernel: a 1-workgroup launch of a few microseconds on the caller's stream)
+      if (mode == MODE_STEP && e->order_calls++ % e->order_every == 0 && e->order_calls > 1) {
+        hipLaunchKernelGGL(tc_order_kernel, dim3(1), dim3(TC_ORDER_NT), 0, main, (const int*)e->k.seg_n, N, e->order_g, e->env_order);
+        HIP_TRY(hipGetLastError());
+      }
+      sa.env_order = e->env_order;
+    }
     hipLaunchKernelGGL(fk, dim3(N), dim3(TC_NT), lds, main, sa);
     HIP_TRY(hipGetLastError());
     e->draw_n = -1;
