@@ -270,7 +270,10 @@ int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const i
  * the caller's stream, no overlap), TC_ENV_GROUPED=0 one wavefront per env in every simulate launch,
  * TC_FIRST_CHUNK_PER_ENV=0, TC_FRAME_STREAMS=1, TC_ENVG_MAP_LDS=0, TC_MULTI_SPLIT=0 a single fused launch in which
  * the same wavefront simulates its env and rasterises each of its frames, TC_SEG_LDS=0 / TC_SEG_LDS_CAP=n draw lists
- * through global memory only / beyond the first n segments. */
+ * through global memory only / beyond the first n segments, TC_FRAME_ORDER=0 frame workgroups in env order (default: the
+ * envs whose last frame had the longest draw list first, so that a dispatch ends with its cheapest frames),
+ * TC_STEP_ORDER=n (tc_step: the envs are re-dealt to the workgroups every n-th step so that heavy and light frames share
+ * a SIMD, default 8; 0 = workgroup w works on env w). */
 typedef struct {
   uint8_t* obs;          /* [K][N][tc_env_obs_bytes] */
   double* reward;        /* [K][N] */

@@ -132,6 +132,7 @@ SWITCHES = [
     {"TC_SEG_LDS": "0"},                  # draw lists through global memory only
     {"TC_SEG_LDS_CAP": "3"},              # every frame mixes an LDS head (3 segments) with a global tail
     {"TC_FRAME_STREAMS": "1"},
+    {"TC_FRAME_ORDER": "0"},              # frame workgroups in env order instead of heaviest first
     {"TC_FIRST_CHUNK_PER_ENV": "0"},
     {"TC_ENV_GROUPED": "0"},              # tc_env_kernel<K,false> for every chunk, not pipelined
     {"TC_ENVG_MAP_LDS": "0"},

@@ -2675,6 +2675,7 @@ struct FrameArgs {
   KArgs a;
   RArgs r;
   const double* pose_rows;  // [rows][N][TC_POSE_ROW]
+  const int* order;         // workgroup x of every grid row draws env order[x] (heaviest frames first: see launch()), or NULL
 };
 // The argument block is read through a pointer the compiler cannot see through, once per stage: the stage's values are
 // then loaded (s_load from the kernarg segment) where they are used instead of all being fetched at kernel entry and
@@ -2689,8 +2690,9 @@ template <int K, bool THICK, int FMT>
 __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame_kernel(FrameArgs fa_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   const FrameArgs& fa = frame_args();
-  const int env = fa.a.env0 + blockIdx.x;
-  if (env >= fa.a.N) return;
+  if ((int)blockIdx.x >= fa.a.N) return;
+  const int env = fa.order ? uni_i(((const __attribute__((address_space(4))) int*)(unsigned long long)fa.order)[blockIdx.x])
+                           : fa.a.env0 + (int)blockIdx.x;
   const int tid = threadIdx.x;
   const int row = fa.r.seg_row0 + blockIdx.y;
   const size_t slot0 = (size_t)row * fa.a.N;
@@ -2788,15 +2790,19 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
 // G - 1 - r % G).
 #define TC_ORDER_NT 1024
 #define TC_ORDER_BINS 256
+// (the keys are read ONCE, into LDS: the lengths may belong to a frame row another stream is about to redraw, and a key
+// that changed between the counting and the placing pass would break the permutation)
 __global__ __launch_bounds__(TC_ORDER_NT) void tc_order_kernel(const int* cost, int N, int G, int* order) {
   __shared__ int hist[TC_ORDER_BINS], cursor[TC_ORDER_BINS];
+  extern __shared__ unsigned char okeys[];  // [N]
   const int t = threadIdx.x;
   for (int b = t; b < TC_ORDER_BINS; b += TC_ORDER_NT) hist[b] = 0;
   __syncthreads();
   for (int i = t; i < N; i += TC_ORDER_NT) {
     int c = cost[i];
     c = c < 0 ? 0 : (c > TC_ORDER_BINS - 1 ? TC_ORDER_BINS - 1 : c);
-    atomicAdd(&hist[TC_ORDER_BINS - 1 - c], 1);  // bin 0 = the heaviest
+    okeys[i] = (unsigned char)(TC_ORDER_BINS - 1 - c);  // bin 0 = the heaviest
+    atomicAdd(&hist[TC_ORDER_BINS - 1 - c], 1);
   }
   __syncthreads();
   if (t == 0) {
@@ -2808,9 +2814,7 @@ __global__ __launch_bounds__(TC_ORDER_NT) void tc_order_kernel(const int* cost, 
   }
   __syncthreads();
   for (int i = t; i < N; i += TC_ORDER_NT) {
-    int c = cost[i];
-    c = c < 0 ? 0 : (c > TC_ORDER_BINS - 1 ? TC_ORDER_BINS - 1 : c);
-    const int r = atomicAdd(&cursor[TC_ORDER_BINS - 1 - c], 1);  // rank among the envs, heaviest first
+    const int r = atomicAdd(&cursor[okeys[i]], 1);  // rank among the envs, heaviest first
     const int row = r / G, j = r - row * G;
     order[row * G + ((row & 1) ? G - 1 - j : j)] = i;
   }
@@ -2892,6 +2896,9 @@ struct tc_env {
   int draw_n;
   int step_lds;  // tc_step_kernel: LDS bytes per workgroup (lds.total grown like frame_lds)
   // cost-aware env order of single-step launches (tc_order_kernel): refreshed every order_every-th tc_step
+  // heaviest-first order of the frame workgroups of a K-step call (TC_FRAME_ORDER=0: env order), one buffer per frame stream
+  int* frame_order[2];       // [N] each, device
+  const int* cost_row[2];    // draw-list lengths of the last frame row launched on that stream (library scratch), or NULL
   int* env_order;   // [N] device, a permutation (identity until the first refresh); NULL = off (TC_STEP_ORDER=0, N % G != 0)
   int order_g;      // G = SIMDs of the device
   int order_every, order_calls;
@@ -3426,6 +3433,18 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
     // of the device and all resident at once (N / G <= 4 wavefronts per SIMD).  TC_STEP_ORDER=n refreshes the order every
     // n-th tc_step (default 8), 0 switches it off.
     e->env_order = nullptr;
+    e->frame_order[0] = e->frame_order[1] = nullptr;
+    e->cost_row[0] = e->cost_row[1] = nullptr;
+    if (!(getenv("TC_FRAME_ORDER") && atoi(getenv("TC_FRAME_ORDER")) == 0) && num_envs <= 60000) {
+      void *f0 = nullptr, *f1 = nullptr;
+      if (hipMalloc(&f0, (size_t)num_envs * sizeof(int)) == hipSuccess && hipMalloc(&f1, (size_t)num_envs * sizeof(int)) == hipSuccess) {
+        e->frame_order[0] = (int*)f0;
+        e->frame_order[1] = (int*)f1;
+      } else {
+        if (f0) (void)hipFree(f0);
+        (void)hipGetLastError();
+      }
+    }
     e->order_calls = 0;
     e->order_every = 8;
     if (const char* so = getenv("TC_STEP_ORDER")) e->order_every = atoi(so) > 0 ? atoi(so) : 0;
@@ -3501,6 +3520,8 @@ extern "C" int tc_env_destroy(tc_env* e) {
   if (e && e->k.seg_g) (void)hipFree(e->k.seg_g);
   if (e && e->k.seg_n) (void)hipFree(e->k.seg_n);
   if (e && e->env_order) (void)hipFree(e->env_order);
+  if (e && e->frame_order[0]) (void)hipFree(e->frame_order[0]);
+  if (e && e->frame_order[1]) (void)hipFree(e->frame_order[1]);
   if (e && e->k.terms) (void)hipFree((void*)e->k.terms);
   if (e && e->k.spawn_tab) (void)hipFree((void*)e->k.spawn_tab);
   if (e && e->noise_hw) (void)hipFree(e->noise_hw);
@@ -3861,6 +3882,7 @@ extern "C" int tc_env_reserve_steps(tc_env* e, int32_t max_chunk_steps) {
   e->segm_g = e->segm_n = nullptr;
   e->pose_rows = nullptr;
   e->ring_rows = 0;
+  e->cost_row[0] = e->cost_row[1] = nullptr;
   const size_t R = (size_t)TC_RING_SLOTS * rows * e->k.N;
   void *p = nullptr, *q = nullptr, *pr = nullptr;
   hipError_t he = hipMalloc(&p, R * e->k.seg_cap * 5 * sizeof(int));
@@ -4049,7 +4071,18 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
         fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
         fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->seg_lds_cap;
+        // Heaviest frames first.  A dispatch ends with a tail -- the chip half empty while the last workgroups finish, ~36 us
+        // of a 16-step dispatch, a fifth of a 5-step one -- and the dispatcher hands workgroups out in index order, so the
+        // envs are sorted by the draw-list lengths of the last frame row drawn on this stream (tc_order_kernel with one
+        // group: plain descending order): the last workgroups to start are then the cheap, mostly empty frames.
+        const int fsi = fs == e->frame_stream2 ? 1 : 0;
+        if (e->frame_order[fsi] && e->cost_row[fsi]) {
+          hipLaunchKernelGGL(tc_order_kernel, dim3(1), dim3(TC_ORDER_NT), (size_t)(N + 15) / 16 * 16, fs, e->cost_row[fsi], N, N, e->frame_order[fsi]);
+          HIP_TRY(hipGetLastError());
+          fa.order = e->frame_order[fsi];
+        }
         hipLaunchKernelGGL(fk, dim3(N, rows), dim3(TC_NT), e->frame_lds, fs, fa);
+        if (e->frame_order[fsi]) e->cost_row[fsi] = e->segm_n + ((size_t)r.seg_row0 + (size_t)rows - 1) * N;
       } else {
 #ifdef TC_DEV_FAST
         auto rk = tc_raster_kernel<true, TC_FMT_CLASSES>;
@@ -4120,7 +4153,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
       // every order_every-th step the envs are re-dealt to the workgroups by the draw-list lengths of the step before
       // (tc_order_kernel: a 1-workgroup launch of a few microseconds on the caller's stream)
       if (mode == MODE_STEP && e->order_calls++ % e->order_every == 0 && e->order_calls > 1) {
-        hipLaunchKernelGGL(tc_order_kernel, dim3(1), dim3(TC_ORDER_NT), 0, main, (const int*)e->k.seg_n, N, e->order_g, e->env_order);
+        hipLaunchKernelGGL(tc_order_kernel, dim3(1), dim3(TC_ORDER_NT), (size_t)(N + 15) / 16 * 16, main, (const int*)e->k.seg_n, N, e->order_g, e->env_order);
         HIP_TRY(hipGetLastError());
       }
       sa.env_order = e->env_order;
