@@ -367,3 +367,30 @@ def test_debug_switch_prints_phase_times(monkeypatch, capsys):
     env.step(act)
     out = capsys.readouterr().out
     assert out.startswith("step: all: ") and "simulate 0.0120 ms" in out and "frames 0.0030 ms" in out and calls == [1, 0]
+
+
+def test_vec_state_dict_resumes_bit_for_bit():
+    """state_dict() / load_state_dict(): a second batch loaded from the first continues exactly like it, auto-reset spawn
+    draws included (checkpoint / resume)"""
+    a = OracleVecEnv(cfg_for("simple_layout"), num_envs=5, autoreset=True, spawn_queue_len=4)
+    a.reset(seed=11)
+    rng = np.random.default_rng(3)
+    def act():
+        return {"car_control": np.stack([rng.uniform(0.3, 1, 5), rng.uniform(-1, 1, 5)], axis=1).astype(np.float32),
+                "maneuver": rng.integers(0, 4, 5).astype(np.int32)}
+    for _ in range(15):
+        a.step(act())
+    sd = a.state_dict()
+    b = OracleVecEnv(cfg_for("simple_layout"), num_envs=5, autoreset=True, spawn_queue_len=4)
+    b.load_state_dict(sd)
+    for _ in range(40):
+        ac = act()
+        oa = a.step(ac)
+        ob = b.step(ac)
+        assert torch.equal(oa[0], ob[0]) and torch.equal(oa[1], ob[1]) and torch.equal(oa[2], ob[2]) and torch.equal(oa[3], ob[3])
+    for k in a.state:
+        assert torch.equal(a.state[k], b.state[k]), k
+    assert a.top_up_spawn_queue() == b.top_up_spawn_queue()
+    assert torch.equal(a._aux["spawn_queue"], b._aux["spawn_queue"])   # the generators continued identically
+    with pytest.raises(ValueError):
+        OracleVecEnv(cfg_for("simple_layout"), num_envs=3).load_state_dict(sd)

@@ -622,6 +622,39 @@ class TinyCarloVecEnv(gym.Env):
                       "tc_env_draw_list_stats")
         return {"mean_segments_per_frame": m.value, "empty_frame_frac": e.value, "max_segments": mx.value, "frames": fr.value}
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self) -> Dict[str, Any]:
+        """Everything needed to continue the batch bit for bit elsewhere or later: car state, last outputs, auto-reset
+        bookkeeping, term counters and the host spawn generators (the reference has no env checkpoint; its whole state
+        is `car.*`, car.py:25-32).  Tensors are cloned to the host."""
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        return {"num_envs": self.num_envs,
+                "state": {k: v.detach().cpu().clone() for k, v in self.state.items()},
+                "out": {k: v.detach().cpu().clone() for k, v in self.out.items()},
+                "aux": {k: v.detach().cpu().clone() for k, v in self._aux.items()},
+                "term_counters": self.term_counters.detach().cpu().clone(),
+                "rng": [None if g is None else g.bit_generator.state for g in self._rngs],
+                "was_reset": self._was_reset}
+
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        if int(sd["num_envs"]) != self.num_envs:
+            raise ValueError(f"state_dict of {sd['num_envs']} envs, this batch has {self.num_envs}")
+        for name, dst in (("state", self.state), ("out", self.out), ("aux", self._aux)):
+            for k, v in sd[name].items():
+                if tuple(v.shape) != tuple(dst[k].shape):
+                    raise ValueError(f"{name}[{k!r}]: shape {tuple(v.shape)} does not fit {tuple(dst[k].shape)} (other config?)")
+                dst[k].copy_(v)
+        self.term_counters.copy_(sd["term_counters"])
+        for i, st in enumerate(sd["rng"]):
+            if st is None:
+                self._rngs[i] = None
+            else:
+                g = np.random.Generator(np.random.PCG64())
+                g.bit_generator.state = st
+                self._rngs[i] = g
+        self._was_reset = bool(sd["was_reset"])
+        self._step_serial += 1
+
     def request_reset(self, mask: torch.Tensor) -> None:
         """Marks envs for re-spawning at the start of the next autoreset step, in addition to the ones the engine
         flagged itself (terminated | truncated).  Torch-side termination wrappers call this with their result;
