@@ -232,7 +232,12 @@ int tc_env_profile_read(tc_env* env, double* simulate_us, double* raster_us, int
 int tc_reset(tc_env* env, const int32_t* spawn_nodes, const uint8_t* mask, uint32_t flags, void* stream);
 
 /* env.py:115-147 for all envs.  car_control: [N][2] (velocity, steering in [-1,1], clipped like env.py:118),
- * dtype TC_F32 or TC_F64; maneuver: [N] in {0,1,2,3}. */
+ * dtype TC_F32 or TC_F64; maneuver: [N] in {0,1,2,3}.
+ * One launch (tc_step_kernel: a wavefront simulates its env, runs the camera and rasterises the frame).  Which env a
+ * workgroup works on is the library's choice -- envs are independent, any assignment gives the same results: when N is
+ * 2-4 rows of one workgroup per SIMD of the device, the envs are re-dealt every TC_STEP_ORDER-th call (default 8; a
+ * one-workgroup tc_order_kernel launch in front of the step) so that frames with long and short draw lists share a
+ * SIMD (workgroups w, w + #SIMDs, ... land on the same SIMD). */
 int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const int32_t* maneuver, uint32_t flags,
             void* stream);
 

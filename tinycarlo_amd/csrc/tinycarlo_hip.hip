@@ -2805,11 +2805,20 @@ __global__ __launch_bounds__(TC_ORDER_NT) void tc_order_kernel(const int* cost, 
     atomicAdd(&hist[TC_ORDER_BINS - 1 - c], 1);
   }
   __syncthreads();
-  if (t == 0) {
-    int acc = 0;
-    for (int b = 0; b < TC_ORDER_BINS; b++) {
-      cursor[b] = acc;
-      acc += hist[b];
+  {  // exclusive prefix sum over the bins: a DPP scan inside each of the first four wavefronts, their totals through LDS
+    __shared__ int wtot[TC_ORDER_BINS / TC_NT];
+    static_assert(TC_ORDER_BINS % TC_NT == 0 && TC_ORDER_BINS <= TC_ORDER_NT, "one thread per bin, whole wavefronts");
+    int v = 0, inc = 0;
+    if (t < TC_ORDER_BINS) {
+      v = hist[t];
+      inc = wave_incl_scan(v, t & (TC_NT - 1));
+      if ((t & (TC_NT - 1)) == TC_NT - 1) wtot[t / TC_NT] = inc;
+    }
+    __syncthreads();
+    if (t < TC_ORDER_BINS) {
+      int base = 0;
+      for (int w = 0; w < t / TC_NT; w++) base += wtot[w];
+      cursor[t] = base + inc - v;
     }
   }
   __syncthreads();
@@ -2899,6 +2908,7 @@ struct tc_env {
   // heaviest-first order of the frame workgroups of a K-step call (TC_FRAME_ORDER=0: env order), one buffer per frame stream
   int* frame_order[2];       // [N] each, device
   const int* cost_row[2];    // draw-list lengths of the last frame row launched on that stream (library scratch), or NULL
+  bool frame_order_valid[2]; // the buffer holds a permutation (a sort has run on it)
   int* env_order;   // [N] device, a permutation (identity until the first refresh); NULL = off (TC_STEP_ORDER=0, N % G != 0)
   int order_g;      // G = SIMDs of the device
   int order_every, order_calls;
@@ -3435,6 +3445,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
     e->env_order = nullptr;
     e->frame_order[0] = e->frame_order[1] = nullptr;
     e->cost_row[0] = e->cost_row[1] = nullptr;
+    e->frame_order_valid[0] = e->frame_order_valid[1] = false;
     if (!(getenv("TC_FRAME_ORDER") && atoi(getenv("TC_FRAME_ORDER")) == 0) && num_envs <= 60000) {
       void *f0 = nullptr, *f1 = nullptr;
       if (hipMalloc(&f0, (size_t)num_envs * sizeof(int)) == hipSuccess && hipMalloc(&f1, (size_t)num_envs * sizeof(int)) == hipSuccess) {
@@ -4076,11 +4087,14 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         // envs are sorted by the draw-list lengths of the last frame row drawn on this stream (tc_order_kernel with one
         // group: plain descending order): the last workgroups to start are then the cheap, mostly empty frames.
         const int fsi = fs == e->frame_stream2 ? 1 : 0;
-        if (e->frame_order[fsi] && e->cost_row[fsi]) {
+        // (a re-sort costs ~5 us of the frame stream -- kernel + launch -- so short dispatches, whose tails already overlap on
+        // two streams, re-sort only once per call and otherwise keep the stream's last order)
+        if (e->frame_order[fsi] && e->cost_row[fsi] && (rows >= 8 || ci < 2)) {
           hipLaunchKernelGGL(tc_order_kernel, dim3(1), dim3(TC_ORDER_NT), (size_t)(N + 15) / 16 * 16, fs, e->cost_row[fsi], N, N, e->frame_order[fsi]);
           HIP_TRY(hipGetLastError());
-          fa.order = e->frame_order[fsi];
+          e->frame_order_valid[fsi] = true;
         }
+        if (e->frame_order[fsi] && e->frame_order_valid[fsi]) fa.order = e->frame_order[fsi];
         hipLaunchKernelGGL(fk, dim3(N, rows), dim3(TC_NT), e->frame_lds, fs, fa);
         if (e->frame_order[fsi]) e->cost_row[fsi] = e->segm_n + ((size_t)r.seg_row0 + (size_t)rows - 1) * N;
       } else {
