@@ -508,7 +508,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": dom, "kernel_us": kernel_s * 1e6,
                      "kernel_us_is": ("HIP-event span of the call's frame dispatches / number of dispatches"
-                                      + (" (consecutive dispatches alternate between two internal streams and overlap: "
+                                      + (" (streamed call: ONE frame dispatch covers the call's steps and runs beside the "
+                                         "simulate launch, its workgroups waiting for their pose rows; the span includes that "
+                                         "wait at the head and the recover pass behind it)" if (two and n_disp == 1 and spd > 1) else
+                                         " (consecutive dispatches alternate between two internal streams and overlap: "
                                          "a span per dispatch, not one dispatch's duration)" if (two and spd < 8 and n_disp > 1) else
                                          " (one stream, back to back: the average dispatch duration)") if two else
                                       "HIP-event duration of the launch"),

@@ -36,16 +36,16 @@ def test_default_workload_line():
     assert set(r["kernels_us"]) == {"tc_envg_kernel", "tc_frame_kernel"} and all(v > 0 for v in r["kernels_us"].values())
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     assert r["algorithmic_bytes_per_env_step"] == 240 + 5 * 64 * 64
-    # 40 steps at up to 128 per call = ONE tc_step_multi call of 40 steps, pipelined inside as 4 chunks of 10; the
-    # roofline is per kernel dispatch (rocprofv3's unit), i.e. per chunk
+    # 40 steps at up to 128 per call = ONE tc_step_multi call of 40 steps, streamed: one simulate launch beside one frame
+    # dispatch of 40 x N workgroups; the roofline is per kernel dispatch (rocprofv3's unit)
     assert d["config"]["entry_point"] == "tc_step_multi" and d["config"]["launches_timed"] == 1 and r["steps_per_call"] == 40
-    assert r["steps_per_dispatch"] == 10 and r["dispatches_per_call"] == 4
+    assert r["steps_per_dispatch"] == 40 and r["dispatches_per_call"] == 1 and "streamed" in r["kernel_us_is"]
     assert r["algorithmic_bytes_per_unit"] == 5 * 64 * 64 + 96     # a frame: the observation + the pose matrix it is drawn from
-    assert r["algorithmic_bytes_per_launch"] == 10 * 4096 * (5 * 64 * 64 + 96)
-    assert abs(r["kernel_us_per_step"] * 10 - r["kernel_us"]) < 1e-6 * r["kernel_us"]
+    assert r["algorithmic_bytes_per_launch"] == 40 * 4096 * (5 * 64 * 64 + 96)
+    assert abs(r["kernel_us_per_step"] * 40 - r["kernel_us"]) < 1e-6 * r["kernel_us"]
     assert abs(r["kernels_us"]["tc_frame_kernel"] - r["kernel_us"]) < 1e-9
     assert abs(r["step_frac"] - (240 + 5 * 64 * 64) * 4096 / (r["step_us"] * 1e-6) / 8e12) < 1e-9
-    # HBM traffic of that dispatch (committed PMC summary, scaled to 10 steps): at least the bytes it must write
+    # HBM traffic of that dispatch (committed PMC summary, scaled to 40 steps): at least the bytes it must write
     assert r["traffic"] is None or 0.9 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 3 * r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and "oracle" in c["sample"]
@@ -59,8 +59,8 @@ def test_other_workloads_and_flags():
     d = _run("--workload", "cfg4", "--envs", "256", "--steps", "10", "--warmup", "2", "--no-cpu-baseline")
     assert d["config"]["envs_per_gpu"] == 256 and d["roofline"]["traffic"] is None     # PMC summary is for the full size only
     assert d["roofline"]["kernel"] == "tc_frame_kernel"    # knuffingen: the K = 9 variant, two camera layer groups
-    assert d["roofline"]["dispatches_per_call"] == 4       # 10 steps: chunks of 3, 3, 3, 1
-    assert d["roofline"]["algorithmic_bytes_per_launch"] == 2.5 * 256 * (5 * 128 * 128 + 96)
+    assert d["roofline"]["dispatches_per_call"] == 1       # 10 steps, streamed
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 10 * 256 * (5 * 128 * 128 + 96)
     # the single-step entry point stays measurable: one tc_step launch per step
     d = _run("--steps", "16", "--warmup", "4", "--steps-per-launch", "0", "--no-cpu-baseline")
     assert d["config"]["entry_point"] == "tc_step" and d["roofline"]["steps_per_dispatch"] == 1

@@ -105,11 +105,25 @@ def run_case(map_name, res, fmt, n, K, seed=0, actions=bench_actions, spawn_queu
 
 
 def test_cfg3_bench_shape_4096_envs_64_steps():
-    """cfg3 as bench.py runs it: 4096 envs, simple_layout, 64x64 classes, autoreset, 64-step calls = 4 chunks of 16 on one
-    frame stream (per-env first chunk, grouped rest, ring slot 0 reused by chunk 3); two calls back to back"""
+    """cfg3 as bench.py runs it: 4096 envs, simple_layout, 64x64 classes, autoreset, 64-step calls, streamed (one simulate
+    launch beside one gated frame launch of 64 x 4096 workgroups); two calls back to back"""
+    n_reset, info = run_case("simple_layout", "r64", "classes", 4096, 64, calls=2)
+    assert info["kernel"] == "tc_envg_kernel+tc_frame_kernel" and info["steps_per_dispatch"] == 64, info
+    assert n_reset > 0, "no env re-spawned inside the calls"
+
+
+def test_cfg3_bench_shape_chunked(monkeypatch):
+    """the same through the chunked pipeline (TC_STREAM=0): 4 chunks of 16 on one frame stream (per-env first chunk, grouped
+    rest, ring slot 0 reused by chunk 3)"""
+    monkeypatch.setenv("TC_STREAM", "0")
     n_reset, info = run_case("simple_layout", "r64", "classes", 4096, 64, calls=2)
     assert info["kernel"] == "tc_envg_kernel+tc_frame_kernel" and info["steps_per_dispatch"] == 16, info
-    assert n_reset > 0, "no env re-spawned inside the calls"
+
+
+def test_streamed_call_longer_than_its_scratch():
+    """a 300-step call runs as segments of 128 steps (TC_STREAM_MAX_ROWS) that reuse the scratch rows"""
+    n_reset, info = run_case("simple_layout", "r64", "classes", 64, 300, seed=3, actions=mixed_actions, spawn_queue_len=64)
+    assert info["steps_per_dispatch"] == 128, info
 
 
 def test_cfg4_bench_shape_knuffingen_r128():
@@ -128,22 +142,29 @@ def test_cfg5_bench_shape_knuffingen_480x640_rgb_banded():
 
 # every switch the shipped library reads (INTEGRATION.md calls them result-neutral): forced one at a time, same oracle
 SWITCHES = [
-    {},                                   # defaults: 40 steps -> 4 chunks of 10, one frame stream, ring wrap
+    {},                                   # defaults: the 40-step call streamed -- one simulate launch, one gated frame launch
+    {"TC_STREAM_TEST_SKIP": "3"},         # a third of the gated frame workgroups give up at once: the gate-2 pass draws them
+    {"TC_STREAM_WAIT_US": "0"},           # no patience at all: whoever finds its row empty gives up and tells the others
     {"TC_SEG_LDS": "0"},                  # draw lists through global memory only
     {"TC_SEG_LDS_CAP": "3"},              # every frame mixes an LDS head (3 segments) with a global tail
-    {"TC_FRAME_STREAMS": "1"},
     {"TC_FRAME_ORDER": "0"},              # frame workgroups in env order instead of heaviest first
-    {"TC_FIRST_CHUNK_PER_ENV": "0"},
-    {"TC_ENV_GROUPED": "0"},              # tc_env_kernel<K,false> for every chunk, not pipelined
     {"TC_ENVG_MAP_LDS": "0"},
-    {"TC_CHUNK": "0"},                    # chunks follow each other on the caller's stream
-    {"TC_CHUNK": "5"},                    # 8 chunks of 5: two frame streams, ring slots reused twice
-    {"TC_CHUNK": "3", "TC_FRAME_STREAMS": "1"},
-    {"TC_MULTI_SPLIT": "0"},              # fused K-step kernel (tc_step_kernel looping)
-    {"TC_FUSE": "0"},                     # camera in the simulate launch + tc_raster_kernel
     {"TC_CAND_GRID": "0"},                # full edge scans instead of the candidate grid
     {"TC_BAND_BYTES": "2048"},            # 64x64 frames rasterised in several LDS bands
     {"TC_GROUPS": "0"},
+    # the chunked pipeline (TC_STREAM=0; also what calls that keep only the last frame go through)
+    {"TC_STREAM": "0"},                   # 40 steps -> 4 chunks of 10, one frame stream, ring wrap
+    {"TC_STREAM": "0", "TC_SEG_LDS_CAP": "3"},
+    {"TC_STREAM": "0", "TC_FRAME_STREAMS": "1"},
+    {"TC_STREAM": "0", "TC_FRAME_ORDER": "0"},
+    {"TC_STREAM": "0", "TC_FIRST_CHUNK_PER_ENV": "0"},
+    {"TC_ENV_GROUPED": "0"},              # tc_env_kernel<K,false> for every chunk, not pipelined
+    {"TC_STREAM": "0", "TC_ENVG_MAP_LDS": "0"},
+    {"TC_CHUNK": "0"},                    # chunks follow each other on the caller's stream
+    {"TC_STREAM": "0", "TC_CHUNK": "5"},  # 8 chunks of 5: two frame streams, ring slots reused twice
+    {"TC_STREAM": "0", "TC_CHUNK": "3", "TC_FRAME_STREAMS": "1"},
+    {"TC_MULTI_SPLIT": "0"},              # fused K-step kernel (tc_step_kernel looping)
+    {"TC_FUSE": "0"},                     # camera in the simulate launch + tc_raster_kernel
 ]
 
 
@@ -216,7 +237,8 @@ def test_step_multi_without_ring_is_refused_and_never_allocates():
 def test_first_step_multi_call_can_be_captured_into_a_graph():
     """after reserve_steps() a K-step call is launches and event edges only: its FIRST call is captured with
     torch.cuda.graph (capture aborts on any allocation / synchronisation) and replayed; twin env steps eagerly"""
-    n, K = 192, 24  # 4 chunks of 6: two internal frame streams forked from and joined back into the capturing stream
+    n, K = 192, 24  # streamed: the internal frame stream is forked from and joined back into the capturing stream; the
+    # replays find the call's two device words reset by the recover pass of the run before
     a = make_env("simple_layout", "r64", "classes", n, autoreset=True)
     b = make_env("simple_layout", "r64", "classes", n, autoreset=True)
     a.reset(seed=7)

@@ -31,7 +31,7 @@ def test_rank_gather_over_rccl_with_one_rank():
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", world_size=1, rank=0, device_id=dev)
     try:
-        n, K = 256, 12  # 4 chunks of 3: two internal frame streams, then the gather on RCCL's stream
+        n, K = 256, 12  # streamed calls: simulate launch on the caller's stream, frames on the internal one, then the gather on RCCL's stream
         env = make_env("simple_layout", "r64", "classes", n, autoreset=True)
         twin = make_env("simple_layout", "r64", "classes", n, autoreset=True)
         env.reset(seed=11)

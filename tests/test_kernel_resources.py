@@ -28,9 +28,11 @@ def test_no_vgpr_spills_in_the_hot_kernels(tmp_path):
         name = re.search(r"\.name:\s+(\S+)", b).group(1)
         g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", b).group(1))  # noqa: E731
         seen[name] = (g("vgpr_count"), g("vgpr_spill_count"), g("private_segment_fixed_size"))
-    hot = [n for n in seen if re.search(r"tc_(frame|step|envg|env|raster)_kernel", n)]
+    hot = [n for n in seen if re.search(r"tc_(frame|frame_recover|step|envg|env|raster)_kernel", n)]
     assert len(hot) >= 5, sorted(seen)
     for n in hot:
         vgpr, spill, scratch = seen[n]
         assert spill == 0 and scratch == 0, (n, "spills VGPRs / uses scratch", seen[n])
+        if "recover" in n:
+            continue  # the pass that draws what a gated frame workgroup gave up on: normally finds nothing to do
         assert vgpr <= 128, (n, "more than 128 VGPRs: fewer than 4 wavefronts per SIMD", vgpr)

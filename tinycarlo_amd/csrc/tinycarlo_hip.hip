@@ -1203,6 +1203,10 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
 // the env's state only through fp (and on the env's camera): the simulate stage computes it once per (step, env) and
 // hands it over in the pose row, so the 64 lanes of a frame wavefront do not each redo the two matrix products.
 #define TC_POSE_ROW 16  // doubles per (step, env) pose row: the 12 entries, padded to 128 bytes
+// "not written yet" in a pose row of a streamed call (a NaN no arithmetic produces: all ones); and the marker a frame
+// workgroup that gave up waiting leaves in place of its draw-list length
+#define TC_POSE_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define TC_FRAME_SKIPPED (-2)
 __device__ __forceinline__ void cam_pose12(const KArgs& a, int env, const FramePose& fp, double* pose) {
   double Ec[12];  // this env's camera (camera.py:23-24,48-50): shared, or its own after tc_env_set_camera_per_env
   if (a.cam_E) {
@@ -1396,6 +1400,9 @@ struct MultiArgs {
   int cam_here;  // tc_env_kernel: 1 = the camera stage (draw list) runs in this kernel, 0 = not (no observation wanted,
                  // or tc_frame_kernel produces the frames from pose_rows)
   double* pose_rows;  // [nsteps][N][TC_POSE_ROW] camera.py:62 pose matrix of every (step, env) for tc_frame_kernel, or NULL
+  unsigned int* resident;  // streamed call (see launch()): every workgroup counts itself in here when it starts, and the
+                           // pose rows are written with device-scope stores (a frame kernel that runs BESIDE this launch
+                           // polls them); NULL otherwise
   int map_lds;        // tc_envg_kernel: 1 = the lane-line edge records (end points + orientations, 48 bytes per edge) are
                       // copied into the workgroup's LDS at kernel start and phase B reads them from there
   int fat_lds;        // tc_envg_kernel: 1 = the lanepath's fat node records (96 bytes per node) sit in LDS too, behind the
@@ -2322,6 +2329,7 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
   __builtin_amdgcn_s_setprio(TC_ENVG_PRIO);
   const StepArgs& s0 = step_args();
   const int lane = threadIdx.x, sub = lane & (TC_EL - 1), grp = lane / TC_EL;
+  if (s0.ma.resident && lane == 0) __hip_atomic_fetch_add(s0.ma.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int N = s0.a.N;
   int env = s0.a.env0 + blockIdx.x * (TC_ENVG_NT / TC_EL) + grp;
   const bool map_lds = s0.ma.map_lds != 0;
@@ -2632,9 +2640,20 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
       double pose[12];
       cam_pose12(sa.a, live ? env : 0, fp, pose);
       if (live && sub == 0) {
-        double2* o = (double2*)(sa.ma.pose_rows + (row0 + env) * TC_POSE_ROW);
+        if (sa.ma.resident) {
+          // streamed call: the frame workgroup of this (step, env) may already be polling the row.  Each entry is one
+          // 8-byte device-scope store (sc1: written through to where every XCD sees it) and validates itself -- the
+          // reader waits until none of the twelve holds TC_POSE_EMPTY any more -- so the stores need no order among
+          // themselves and this wavefront waits for none of them.
+          unsigned long long* o = (unsigned long long*)(sa.ma.pose_rows + (row0 + env) * TC_POSE_ROW);
 #pragma unroll
-        for (int i = 0; i < 6; i++) o[i] = make_double2(pose[2 * i], pose[2 * i + 1]);
+          for (int i = 0; i < 12; i++)
+            __hip_atomic_store(o + i, (unsigned long long)__double_as_longlong(pose[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          double2* o = (double2*)(sa.ma.pose_rows + (row0 + env) * TC_POSE_ROW);
+#pragma unroll
+          for (int i = 0; i < 6; i++) o[i] = make_double2(pose[2 * i], pose[2 * i + 1]);
+        }
       }
     }
     TSTAMP(15);
@@ -2676,6 +2695,14 @@ struct FrameArgs {
   RArgs r;
   const double* pose_rows;  // [rows][N][TC_POSE_ROW]
   const int* order;         // workgroup x of every grid row draws env order[x] (heaviest frames first: see launch()), or NULL
+  // Streamed call (launch()): this kernel runs BESIDE the simulate launch that produces its pose rows.
+  int gate;                 // 0: the rows are complete (written by an earlier launch); 1: wait for the row (bounded: gate_ticks);
+                            // 2: tc_frame_recover_kernel, behind the simulate launch: draws what a gate-1 workgroup gave up on
+  int recover_rows;         // gate 2: rows of the call
+  unsigned int* abort_word; // gate 1: set by the first workgroup whose wait ran out; the others then give up at once
+  unsigned int* resident;   // gate 2: workgroup 0 clears this and abort_word for the next call
+  long long gate_ticks;     // gate 1: how long a workgroup waits for its row, in 100 MHz ticks
+  int gate_test;            // tests only: gate-1 workgroups with (row + env) % gate_test == 0 give up without waiting
 };
 // The argument block is read through a pointer the compiler cannot see through, once per stage: the stage's values are
 // then loaded (s_load from the kernarg segment) where they are used instead of all being fetched at kernel entry and
@@ -2686,23 +2713,57 @@ __device__ __forceinline__ const FrameArgs& frame_args() {
   asm volatile("" : "+s"(p));
   return *(const FrameArgs*)(FrameArgsConst)p;
 }
+// One frame: `rowy` is the frame's row in the launch (its step), `env` its env.
 template <int K, bool THICK, int FMT>
-__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame_kernel(FrameArgs fa_unused) {
-  extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void frame_one(unsigned char* smem, const int env, const int rowy) {
   const FrameArgs& fa = frame_args();
-  if ((int)blockIdx.x >= fa.a.N) return;
-  const int env = fa.order ? uni_i(((const __attribute__((address_space(4))) int*)(unsigned long long)fa.order)[blockIdx.x])
-                           : fa.a.env0 + (int)blockIdx.x;
   const int tid = threadIdx.x;
-  const int row = fa.r.seg_row0 + blockIdx.y;
+  const int row = fa.r.seg_row0 + rowy;
   const size_t slot0 = (size_t)row * fa.a.N;
-  // the pose row the simulate launch wrote for this (step, env): one address for the whole wavefront, read through the
-  // scalar cache (written by an earlier launch: complete and visible before this kernel started)
-  const __attribute__((address_space(4))) double* pr =
-      (const __attribute__((address_space(4))) double*)(unsigned long long)(fa.pose_rows + (slot0 + env) * TC_POSE_ROW);
   double pose[12];
+  if (fa.gate) {
+    // Streamed call: the row may not exist yet.  Lanes 0..11 read one entry each with device-scope loads (sc1: neither
+    // this CU's caches nor this XCD's L2 may answer with an older copy; the scalar cache is out of the question) until
+    // none holds TC_POSE_EMPTY; the values then move to scalar registers.  Rows are dispatched in step order and the
+    // simulate launch is resident before this kernel starts (tc_gate_kernel), so the wait ends -- but nothing here relies
+    // on that: a wait that outlasts gate_ticks marks the frame skipped, tells the others and leaves, and
+    // tc_frame_recover_kernel, behind the simulate launch, draws it.
+    unsigned long long* prow = (unsigned long long*)(fa.pose_rows + (slot0 + env) * TC_POSE_ROW);
+    unsigned long long v = 0;
+    bool give_up = fa.gate == 1 && fa.gate_test > 0 && (row + env) % fa.gate_test == 0;
+    long long t0 = 0;
+    while (!give_up) {
+      v = tid < 12 ? __hip_atomic_load(prow + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      if (__ballot(v == TC_POSE_EMPTY) == 0 || fa.gate == 2) break;
+      const long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > fa.gate_ticks || __hip_atomic_load(fa.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        give_up = true;
+      else
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (give_up) {
+      if (tid == 0) {
+        if (t0 != 0) __hip_atomic_store(fa.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (not the test's skips)
+        fa.a.seg_n[slot0 + env] = TC_FRAME_SKIPPED;
+      }
+      return;
+    }
+    const unsigned int vlo = (unsigned int)v, vhi = (unsigned int)(v >> 32);
 #pragma unroll
-  for (int i = 0; i < 12; i++) pose[i] = pr[i];
+    for (int i = 0; i < 12; i++) {
+      const unsigned long long q = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)vlo, i) |
+                                   ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)vhi, i) << 32);
+      pose[i] = __longlong_as_double((long long)q);
+    }
+  } else {
+    // the pose row the simulate launch wrote for this (step, env): one address for the whole wavefront, read through the
+    // scalar cache (written by an earlier launch: complete and visible before this kernel started)
+    const __attribute__((address_space(4))) double* pr =
+        (const __attribute__((address_space(4))) double*)(unsigned long long)(fa.pose_rows + (slot0 + env) * TC_POSE_ROW);
+#pragma unroll
+    for (int i = 0; i < 12; i++) pose[i] = pr[i];
+  }
   MapCache<K> mc;
   int nseg;
   unsigned int used;
@@ -2716,10 +2777,53 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame
   else
     lds_sync();
   const FrameArgs& fr = frame_args();
-  raster_body<THICK, FMT>(fr.r, smem, env, fr.r.obs + (size_t)blockIdx.y * fr.r.obs_row_stride, tid, slot0, nseg, used,
-                          fr.r.noise_row0 + (int)blockIdx.y);
-  if (tid == 0) frame_args().a.seg_n[slot0 + env] = nseg;  // workload statistics only; nothing waits for it
+  raster_body<THICK, FMT>(fr.r, smem, env, fr.r.obs + (size_t)rowy * fr.r.obs_row_stride, tid, slot0, nseg, used,
+                          fr.r.noise_row0 + rowy);
+  {
+    const FrameArgs& fe = frame_args();
+    if (tid == 0) fe.a.seg_n[slot0 + env] = nseg;  // workload statistics, the next dispatch's order, "drawn" for the recover pass
+    // a streamed call's row goes back to "not written yet" for the next call (which starts behind this kernel)
+    if (fe.gate && tid < 12)
+      __hip_atomic_store((unsigned long long*)(fe.pose_rows + (slot0 + env) * TC_POSE_ROW) + tid, TC_POSE_EMPTY, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
   TSTAMP_DUMP(env);
+}
+
+template <int K, bool THICK, int FMT>
+__global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame_kernel(FrameArgs fa_unused) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const FrameArgs& fa = frame_args();
+  if ((int)blockIdx.x >= fa.a.N) return;
+  const int env = fa.order ? uni_i(((const __attribute__((address_space(4))) int*)(unsigned long long)fa.order)[blockIdx.x])
+                           : fa.a.env0 + (int)blockIdx.x;
+  frame_one<K, THICK, FMT>(smem, env, (int)blockIdx.y);
+}
+
+// The pass behind a streamed call's simulate launch: one workgroup per env looks through the call's rows for frames a
+// gated workgroup gave up on (normally none: one strided read per row block and out) and draws them itself, one after
+// the other, with gate = 2 (the row is there: read once, no waiting).  Workgroup 0 resets the call's two words.
+// Never on the hot path, so what the step loop around a ~10 k-instruction body costs in registers does not matter.
+template <int K, bool THICK, int FMT>
+__global__ __launch_bounds__(TC_NT) void tc_frame_recover_kernel(FrameArgs fa_unused) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const FrameArgs& fa = frame_args();
+  const int env = (int)blockIdx.x, tid = threadIdx.x;
+  if (env >= fa.a.N) return;
+  if (env == 0 && tid == 0) {
+    __hip_atomic_store(fa.abort_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fa.resident, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int rows = fa.recover_rows;
+  bool any = false;
+  for (int r = tid; r < rows; r += TC_NT) any |= ((const volatile int*)fa.a.seg_n)[(size_t)(fa.r.seg_row0 + r) * fa.a.N + env] == TC_FRAME_SKIPPED;
+  if (__ballot(any) == 0) return;
+  for (int r = 0; r < rows; r++) {
+    const FrameArgs& fb = frame_args();
+    if (uni_i(((const volatile int*)fb.a.seg_n)[(size_t)(fb.r.seg_row0 + r) * fb.a.N + env]) != TC_FRAME_SKIPPED) continue;
+    frame_one<K, THICK, FMT>(smem, env, r);
+    __syncthreads();  // the next frame reuses the LDS
+  }
 }
 
 // All stages in one launch: the same wavefront simulates its env, runs the camera and rasterises the frame.  The form
@@ -2829,6 +2933,16 @@ __global__ __launch_bounds__(TC_ORDER_NT) void tc_order_kernel(const int* cost, 
   }
 }
 
+// Streamed call: holds the frame stream until every workgroup of the simulate launch on the caller's stream has started
+// (they count themselves into *resident).  One wavefront, so it cannot keep them off the chip itself; the frame
+// kernel behind it in stream order then finds its producers resident whatever it fills the chip with.  Bounded: after
+// `ticks` (100 MHz) it lets the frame kernel go regardless, whose workgroups have a bound of their own.
+__global__ __launch_bounds__(64) void tc_gate_kernel(const unsigned int* resident, unsigned int want, long long ticks) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < ticks)
+    __builtin_amdgcn_s_sleep(2);
+}
+
 typedef void (*fused_kern_t)(StepArgs);
 // TC_DEV_FAST (make dev): only the K = 5 / thick / classes variants are instantiated -- a compile of seconds instead of
 // minutes for kernel work on cfg3.  Never shipped: the default build has no such macro.
@@ -2850,6 +2964,16 @@ static frame_kern_t pick_frame(bool thick, bool cls) {
 #else
   return thick ? (cls ? tc_frame_kernel<K, true, TC_FMT_CLASSES> : tc_frame_kernel<K, true, TC_FMT_RGB>)
                : (cls ? tc_frame_kernel<K, false, TC_FMT_CLASSES> : tc_frame_kernel<K, false, TC_FMT_RGB>);
+#endif
+}
+
+template <int K>
+static frame_kern_t pick_recover(bool thick, bool cls) {
+#ifdef TC_DEV_FAST
+  return tc_frame_recover_kernel<5, true, TC_FMT_CLASSES>;
+#else
+  return thick ? (cls ? tc_frame_recover_kernel<K, true, TC_FMT_CLASSES> : tc_frame_recover_kernel<K, true, TC_FMT_RGB>)
+               : (cls ? tc_frame_recover_kernel<K, false, TC_FMT_CLASSES> : tc_frame_recover_kernel<K, false, TC_FMT_RGB>);
 #endif
 }
 
@@ -2903,6 +3027,19 @@ struct tc_env {
   // row, rows) pairs of the last K-step call, or the per-env list of the last single step (draw_n < 0)
   int draw_rows[TC_RING_SLOTS][2];
   int draw_n;
+  const int* draw_base;  // the [rows][N] array the pairs index: the ring's, or the streamed call's
+  // Streamed K-step calls (TC_STREAM=0: chunked as above): ONE simulate launch for all steps of the call and ONE frame
+  // launch beside it whose workgroups wait for their pose row -- see launch().  Scratch for st_rows steps
+  // (tc_env_reserve_steps); longer calls run as segments of st_rows steps.
+  int stream;            // 1 = on
+  int st_rows;
+  int* st_segm_g;        // [st_rows][N][seg_cap][5]
+  int* st_segm_n;        // [st_rows][N]
+  double* st_pose;       // [st_rows][N][TC_POSE_ROW], every entry TC_POSE_EMPTY between calls
+  unsigned int* st_words;  // [0] simulate workgroups resident, [1] "a frame workgroup gave up waiting"
+  long long gate_ticks;  // bound of a frame workgroup's wait (100 MHz ticks; TC_STREAM_WAIT_US)
+  int gate_test;         // TC_STREAM_TEST_SKIP=m (tests): frames with (row + env) % m == 0 are left to the gate-2 pass
+  hipEvent_t start_ev;
   int step_lds;  // tc_step_kernel: LDS bytes per workgroup (lds.total grown like frame_lds)
   // cost-aware env order of single-step launches (tc_order_kernel): refreshed every order_every-th tc_step
   // heaviest-first order of the frame workgroups of a K-step call (TC_FRAME_ORDER=0: env order), one buffer per frame stream
@@ -3212,10 +3349,23 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   e->frame_streams = 2;
   if (const char* fsn = getenv("TC_FRAME_STREAMS")) e->frame_streams = atoi(fsn) == 1 ? 1 : 2;
   memset(e->prof_piped, 0, sizeof(e->prof_piped));
+  e->stream = 1;
+  if (const char* st = getenv("TC_STREAM")) e->stream = atoi(st) != 0;
+  e->st_rows = 0;
+  e->st_segm_g = e->st_segm_n = nullptr;
+  e->st_pose = nullptr;
+  e->st_words = nullptr;
+  e->draw_base = nullptr;
+  e->start_ev = nullptr;
+  e->gate_ticks = 5000 * 100LL;  // 5 ms
+  if (const char* gw = getenv("TC_STREAM_WAIT_US")) e->gate_ticks = (long long)(atof(gw) * 100.0);
+  e->gate_test = 0;
+  if (const char* gt = getenv("TC_STREAM_TEST_SKIP")) e->gate_test = atoi(gt) > 0 ? atoi(gt) : 0;
   if (hipStreamCreateWithFlags(&e->frame_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&e->frame_stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->frames_ev2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->sim_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->start_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->frames_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->call_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->slot_ev[0], hipEventDisableTiming) != hipSuccess ||
@@ -3523,6 +3673,11 @@ extern "C" int tc_env_destroy(tc_env* e) {
     if (e->frame_stream2) (void)hipStreamDestroy(e->frame_stream2);
     if (e->frames_ev2) (void)hipEventDestroy(e->frames_ev2);
     if (e->sim_ev) (void)hipEventDestroy(e->sim_ev);
+    if (e->start_ev) (void)hipEventDestroy(e->start_ev);
+    if (e->st_segm_g) (void)hipFree(e->st_segm_g);
+    if (e->st_segm_n) (void)hipFree(e->st_segm_n);
+    if (e->st_pose) (void)hipFree(e->st_pose);
+    if (e->st_words) (void)hipFree(e->st_words);
     if (e->frames_ev) (void)hipEventDestroy(e->frames_ev);
   }
   if (e && e->segm_g) (void)hipFree(e->segm_g);
@@ -3881,8 +4036,55 @@ static bool fused_path(const tc_env* e, uint32_t flags) {
   return do_raster && e->fuse && e->kvar != 13;
 }
 
+#define TC_STREAM_MAX_ROWS 128
+// scratch of streamed calls: rows for min(max_call_steps, TC_STREAM_MAX_ROWS) steps
+static int reserve_stream(tc_env* e, int max_call_steps) {
+  int rows = max_call_steps < TC_STREAM_MAX_ROWS ? max_call_steps : TC_STREAM_MAX_ROWS;
+  if (rows < 2) rows = 2;
+  if (e->st_rows >= rows) return TC_OK;
+  HIP_TRY(hipDeviceSynchronize());  // earlier launches may still use the old arrays
+  if (e->st_segm_g) (void)hipFree(e->st_segm_g);
+  if (e->st_segm_n) (void)hipFree(e->st_segm_n);
+  if (e->st_pose) (void)hipFree(e->st_pose);
+  e->st_segm_g = e->st_segm_n = nullptr;
+  e->st_pose = nullptr;
+  e->st_rows = 0;
+  e->cost_row[0] = e->cost_row[1] = nullptr;
+  e->draw_n = 0;
+  const size_t R = (size_t)rows * e->k.N;
+  void *p = nullptr, *q = nullptr, *pr = nullptr;
+  hipError_t he = hipMalloc(&p, R * e->k.seg_cap * 5 * sizeof(int));
+  if (he == hipSuccess) he = hipMalloc(&q, R * sizeof(int));
+  if (he == hipSuccess) he = hipMalloc(&pr, R * TC_POSE_ROW * sizeof(double));
+  if (he == hipSuccess && !e->st_words) {
+    void* w = nullptr;
+    he = hipMalloc(&w, 256);
+    if (he == hipSuccess) he = hipMemset(w, 0, 256);
+    e->st_words = (unsigned int*)w;
+  }
+  if (he == hipSuccess) he = hipMemset(pr, 0xFF, R * TC_POSE_ROW * sizeof(double));  // every entry TC_POSE_EMPTY
+  if (he == hipSuccess) he = hipMemset(q, 0, R * sizeof(int));
+  if (he == hipSuccess) he = hipDeviceSynchronize();
+  if (he != hipSuccess) {
+    if (p) (void)hipFree(p);
+    if (q) (void)hipFree(q);
+    if (pr) (void)hipFree(pr);
+    set_err(std::string("hipMalloc(scratch of streamed K-step calls): ") + hipGetErrorString(he));
+    return TC_E_NOMEM;
+  }
+  e->st_segm_g = (int*)p;
+  e->st_segm_n = (int*)q;
+  e->st_pose = (double*)pr;
+  e->st_rows = rows;
+  return TC_OK;
+}
+
 extern "C" int tc_env_reserve_steps(tc_env* e, int32_t max_chunk_steps) {
   if (!e || max_chunk_steps < 1) return TC_E_INVALID;
+  if (e->stream && e->env_grouped && e->pipe) {
+    int rc = reserve_stream(e, max_chunk_steps);
+    if (rc != TC_OK) return rc;
+  }
   int rows = max_chunk_steps < e->chunk ? max_chunk_steps : e->chunk;
   if (rows < 2) rows = 2;  // (a pipelined call never uses chunks of fewer than 2 steps)
   if (e->ring_rows >= rows) return TC_OK;
@@ -3989,9 +4191,131 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
     bool first_frames = true;
     bool used_fs[2] = {false, false};
     e->draw_n = 0;
+    e->draw_base = e->segm_n;
     const int C = e->k.m.C;
+    // Streamed form (default when every step's frame is wanted).  The chunked pipeline below pays for its structure: the
+    // first chunk's simulate launch overlaps with nothing, and every frame dispatch ends in a tail with the chip half empty
+    // -- a quarter of a 20-step call.  Here the whole call (or a segment of st_rows steps) is ONE simulate launch on the
+    // caller's stream and ONE frame launch of steps x N workgroups on the internal stream that starts right away, beside
+    // it: a frame workgroup polls its pose row until the simulate launch has written it (device-scope loads; every entry
+    // validates itself, tc_frame_kernel).  Only the first step is exposed, and there is one tail per call.
+    //   frame stream: [order kernel] [tc_gate_kernel: until the simulate workgroups are resident] [tc_frame_kernel, gate 1]
+    //                 (wait: simulate launch done) [tc_frame_recover_kernel: whatever a gate-1 workgroup gave up on]
+    // Every wait on the device is bounded (gate_ticks), and what a bound cuts short the recover pass completes: the
+    // result never depends on how the two launches were scheduled.
+    const bool streamed = piped && e->stream && e->st_rows >= 2 && e->st_words;
+    if (streamed) {
+      e->draw_base = e->st_segm_n;
+      const int seg_steps = e->st_rows;
+      int si = 0;
+      for (int c0 = 0, cn = 0; c0 < nsteps; c0 += cn, si++) {
+        cn = nsteps - c0 < seg_steps ? nsteps - c0 : seg_steps;
+        const size_t r0 = (size_t)c0 * N;
+        // a later segment reuses the scratch rows: the frames of the one before must be drawn (and its rows cleared)
+        if (si > 0) HIP_TRY(hipStreamWaitEvent(main, e->slot_ev[0], 0));
+        HIP_TRY(hipEventRecord(e->start_ev, main));
+        StepArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.a = e->k;
+        sa.a.env0 = 0;
+        sa.a.seg_g = e->st_segm_g;
+        sa.a.seg_n = e->st_segm_n;
+        sa.ma = ma;
+        sa.ma.nsteps = cn;
+        sa.ma.seg_rows = cn > 1 ? cn : 2;
+        sa.ma.cam_here = 0;
+        sa.ma.pose_rows = e->st_pose;
+        sa.ma.resident = e->st_words;
+        if (roll) {
+          tc_rollout& q = sa.ma.roll;
+          q.obs = roll->obs + r0 * (size_t)e->obs_bytes;
+          q.reward = roll->reward ? roll->reward + r0 : nullptr;
+          q.terminated = roll->terminated ? roll->terminated + r0 : nullptr;
+          q.truncated = roll->truncated ? roll->truncated + r0 : nullptr;
+          q.cte = roll->cte ? roll->cte + r0 : nullptr;
+          q.heading_error = roll->heading_error ? roll->heading_error + r0 : nullptr;
+          q.status = roll->status ? roll->status + r0 : nullptr;
+          q.x = roll->x ? roll->x + r0 : nullptr;
+          q.y = roll->y ? roll->y + r0 : nullptr;
+          q.theta = roll->theta ? roll->theta + r0 : nullptr;
+          q.velocity = roll->velocity ? roll->velocity + r0 : nullptr;
+          q.laneline_distances = roll->laneline_distances ? roll->laneline_distances + r0 * C : nullptr;
+          q.nearest_edge = roll->nearest_edge ? roll->nearest_edge + r0 * C : nullptr;
+          q.local_path = roll->local_path ? roll->local_path + r0 * 8 : nullptr;
+          q.lp_len = roll->lp_len ? roll->lp_len + r0 : nullptr;
+        }
+        sa.mode = mode;
+        sa.cdtype = cdtype;
+        sa.flags = flags;
+        sa.car_control = (const char*)cc + r0 * 2 * esz;
+        sa.maneuver = man + r0;
+        sa.spawn_nodes = spawn;
+        sa.mask = mask;
+        const size_t map_bytes = ((size_t)e->k.m.total_edges * 48 + 15) / 16 * 16, fat_bytes = (size_t)e->k.m.lpN * sizeof(LpNode);
+        sa.ma.map_lds = (e->envg_map_lds && map_bytes <= 40 * 1024) ? 1 : 0;
+        sa.ma.fat_lds = (e->envg_map_lds && fat_bytes <= 56 * 1024) ? 1 : 0;
+        const unsigned int sim_wgs = (unsigned int)((N + TC_ENVG_NT / TC_EL - 1) / (TC_ENVG_NT / TC_EL));
+        hipLaunchKernelGGL(tc_envg_kernel, dim3(sim_wgs), dim3(TC_ENVG_NT), (sa.ma.map_lds ? map_bytes : 0) + (sa.ma.fat_lds ? fat_bytes : 0),
+                           main, sa);
+        HIP_TRY(hipGetLastError());
+        if (prof && c0 + cn >= nsteps) HIP_TRY(hipEventRecord(e->ev[1][slot], main));
+        HIP_TRY(hipEventRecord(e->sim_ev, main));
+        // ---- the frame stream
+        hipStream_t fs = e->frame_stream;
+        // heaviest frames first, by the last row of the call before (see the chunked form below).  Depends on nothing but
+        // this stream's own past, so it runs while the simulate launch starts
+        if (e->frame_order[0] && e->cost_row[0]) {
+          hipLaunchKernelGGL(tc_order_kernel, dim3(1), dim3(TC_ORDER_NT), (size_t)(N + 15) / 16 * 16, fs, e->cost_row[0], N, N, e->frame_order[0]);
+          HIP_TRY(hipGetLastError());
+          e->frame_order_valid[0] = true;
+        }
+        HIP_TRY(hipStreamWaitEvent(fs, e->start_ev, 0));
+        RArgs r = make_rargs(e, e->st_segm_g, e->st_segm_n, e->k.seg_cap, nullptr, flags, 0, roll->obs + r0 * (size_t)e->obs_bytes,
+                             mode == MODE_STEP);
+        r.seg_row0 = 0;
+        r.noise_row0 = c0;
+        r.obs_row_stride = (long long)N * (long long)e->obs_bytes;
+        FrameArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.a = e->k;
+        fa.a.dbg = flags;
+        fa.a.env0 = 0;
+        fa.a.seg_g = e->st_segm_g;
+        fa.a.seg_n = e->st_segm_n;
+        fa.r = r;
+        fa.pose_rows = e->st_pose;
+        fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
+        fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->seg_lds_cap;
+        fa.abort_word = e->st_words + 1;
+        fa.resident = e->st_words;
+        fa.gate_ticks = e->gate_ticks;
+        fa.gate_test = e->gate_test;
+        if (e->frame_order[0] && e->frame_order_valid[0]) fa.order = e->frame_order[0];
+        hipLaunchKernelGGL(tc_gate_kernel, dim3(1), dim3(64), 0, fs, (const unsigned int*)e->st_words, sim_wgs, e->gate_ticks);
+        HIP_TRY(hipGetLastError());
+        if (prof && si == 0) HIP_TRY(hipEventRecord(e->ev[3][slot], fs));
+        frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
+        fa.gate = 1;
+        hipLaunchKernelGGL(fk, dim3(N, cn), dim3(TC_NT), e->frame_lds, fs, fa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamWaitEvent(fs, e->sim_ev, 0));
+        fa.gate = 2;
+        fa.recover_rows = cn;
+        fa.order = nullptr;
+        frame_kern_t rk = kv == 5 ? pick_recover<5>(thick, cls) : kv == 8 ? pick_recover<8>(thick, cls) : pick_recover<9>(thick, cls);
+        hipLaunchKernelGGL(rk, dim3(N), dim3(TC_NT), e->frame_lds, fs, fa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e->slot_ev[0], fs));
+        if (e->frame_order[0]) e->cost_row[0] = e->st_segm_n + (size_t)(cn - 1) * N;
+        used_fs[0] = true;
+        const int keep = cn < 3 * 16 ? cn : 3 * 16;  // the statistics cover the same span as a chunked call's ring
+        e->draw_rows[0][0] = cn - keep;
+        e->draw_rows[0][1] = keep;
+        e->draw_n = 1;
+      }
+    }
     int ci = 0;
-    for (int c0 = 0, cn = 0; c0 < nsteps; c0 += cn, ci++) {
+    for (int c0 = 0, cn = 0; !streamed && c0 < nsteps; c0 += cn, ci++) {
       cn = nsteps - c0 < chunk ? nsteps - c0 : chunk;
       const size_t r0 = (size_t)c0 * N;                 // first [step][env] row of this chunk in the caller's arrays
       const int rslot = ci % TC_RING_SLOTS;
@@ -4270,7 +4594,7 @@ extern "C" int tc_env_draw_list_stats(tc_env* e, double* mean_segments, double* 
     if (rc != TC_OK) return rc;
   } else {
     for (int i = 0; i < e->draw_n; i++) {
-      int rc = take(e->segm_n + (size_t)e->draw_rows[i][0] * N, (size_t)e->draw_rows[i][1] * N);
+      int rc = take(e->draw_base + (size_t)e->draw_rows[i][0] * N, (size_t)e->draw_rows[i][1] * N);
       if (rc != TC_OK) return rc;
     }
   }
@@ -4289,7 +4613,9 @@ extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t n_ste
   if (fused) *fused = f ? 1 : 0;
   if (kvar) *kvar = e->kvar;
   const bool frames = n_steps > 1 && do_raster && !f && e->fuse && e->kvar != 13;
-  if (steps_per_dispatch) *steps_per_dispatch = f ? n_steps : chunk_steps(e, n_steps, frames, true);
+  const bool streamed = frames && e->env_grouped && e->pipe && e->stream && e->st_rows >= 2;  // (as in launch())
+  if (steps_per_dispatch)
+    *steps_per_dispatch = f ? n_steps : streamed ? (n_steps < e->st_rows ? n_steps : e->st_rows) : chunk_steps(e, n_steps, frames, true);
   if (name && name_cap > 0)
     snprintf(name, (size_t)name_cap, "%s",
              f ? "tc_step_kernel"
