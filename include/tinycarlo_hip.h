@@ -256,27 +256,42 @@ int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const i
  * What is launched (tc_env_launch_info reports it):
  *   - no observation wanted: ONE launch of tc_env_kernel, one wavefront per env looping over the K steps with the
  *     env's state parked in LDS.
- *   - observations: the steps are issued in chunks of at most 16 steps (a quarter of the call if that is less).  Per
- *     chunk a SIMULATE launch -- tc_envg_kernel: 8 lanes per env, 8 envs per wavefront, state in registers, looping
- *     over the chunk's steps and leaving one 128-byte pose row (camera.py:62) per (step, env); the first chunk of a
- *     multi-chunk call goes through tc_env_kernel instead (short rather than cheap: nothing overlaps it) -- and a
- *     FRAME launch -- tc_frame_kernel: one workgroup per (step, env) of the chunk, camera stage + raster stage + the
- *     observation store.  With rollout->obs the frame launches run on an internal stream behind their chunk's simulate
- *     launch, so chunk c+1 is simulated while chunk c is drawn; the internal stream is joined back into the caller's
- *     before the call's work there ends, so everything still completes in stream order.  Calls whose chunks are
- *     shorter than 8 steps alternate their frame launches between two internal streams.  Without rollout->obs only
- *     the last step's frame is drawn (the others would be overwritten).
+ *   - observations into rollout->obs (every step's frame wanted), STREAMED -- the default: per call (per segment of
+ *     128 steps of a longer call) ONE simulate launch on the caller's stream -- tc_envg_kernel: 8 lanes per env, 8 envs
+ *     per wavefront, state in registers, looping over the steps and leaving one 128-byte pose row (camera.py:62) per
+ *     (step, env) -- and, on an internal stream, ONE frame launch that starts at once and runs BESIDE it --
+ *     tc_frame_kernel: one workgroup per (step, env), camera stage + raster stage + the observation store; a workgroup
+ *     first polls its pose row with device-scope loads until the simulate launch has written it (each of the twelve
+ *     entries validates itself: a row is "not written yet" while any entry holds an all-ones NaN, and the frame
+ *     workgroup puts that pattern back when it is done).  Only the call's first step is exposed, and the chip drains
+ *     once per call instead of once per chunk.  Around the two launches, on the internal stream: tc_order_kernel
+ *     (heaviest frames first, see TC_FRAME_ORDER), tc_gate_kernel (one wavefront: holds the frame launch back until
+ *     every simulate workgroup has started, so the frame workgroups can fill the chip without keeping their producers
+ *     off it) and, behind the simulate launch, tc_frame_recover_kernel.  EVERY wait on the device is bounded
+ *     (TC_STREAM_WAIT_US, default 5000): a frame workgroup whose wait runs out marks its frame skipped, tells the others
+ *     to stop waiting and leaves, and the recover kernel -- one workgroup per env, normally one look at the call's
+ *     rows and out -- draws the skipped frames from the then complete rows.  The result therefore never depends on
+ *     how the two launches were scheduled, only the time does.  The internal stream is joined back into the caller's
+ *     before the call's work there ends, so everything completes in stream order.
+ *   - the same, CHUNKED (TC_STREAM=0, and the form of calls without rollout->obs, where only the last step's frame
+ *     is drawn): the steps are issued in chunks of at most 16 steps (a quarter of the call if that is less).  Per
+ *     chunk a simulate launch (tc_envg_kernel; the first chunk of a multi-chunk call goes through tc_env_kernel: short
+ *     rather than cheap, nothing overlaps it) and a frame launch (tc_frame_kernel, pose rows complete: no polling)
+ *     on an internal stream behind it, so chunk c+1 is simulated while chunk c is drawn.  Calls whose chunks are
+ *     shorter than 8 steps alternate their frame launches between two internal streams.
  *   - maps whose largest lane-line layer exceeds 576 nodes / edges (K = 13 variant) and TC_FUSE=0: the camera stage
  *     runs inside the simulate launch and tc_raster_kernel draws the frames.
- * The pose rows and draw lists of the chunks in flight live in a library-owned ring sized by tc_env_reserve_steps,
- * which must have been called once before the first K-step call that renders (n_steps > 1 with an observation):
- * tc_step_multi itself never allocates and never waits for the device; without a ring it returns TC_E_INVALID.
- * Env vars (all result-neutral, read at tc_env_create): TC_CHUNK=n steps per chunk (0: chunks follow each other on
- * the caller's stream, no overlap), TC_ENV_GROUPED=0 one wavefront per env in every simulate launch,
- * TC_FIRST_CHUNK_PER_ENV=0, TC_FRAME_STREAMS=1, TC_ENVG_MAP_LDS=0, TC_MULTI_SPLIT=0 a single fused launch in which
- * the same wavefront simulates its env and rasterises each of its frames, TC_SEG_LDS=0 / TC_SEG_LDS_CAP=n draw lists
- * through global memory only / beyond the first n segments, TC_FRAME_ORDER=0 frame workgroups in env order (default: the
- * envs whose last frame had the longest draw list first, so that a dispatch ends with its cheapest frames),
+ * The pose rows and draw lists in flight live in library-owned scratch sized by tc_env_reserve_steps, which must have
+ * been called once before the first K-step call that renders (n_steps > 1 with an observation): tc_step_multi itself
+ * never allocates and never waits for the device; without the scratch it returns TC_E_INVALID.
+ * Env vars (all result-neutral, read at tc_env_create): TC_STREAM=0 chunked form; TC_STREAM_WAIT_US=t bound of a frame
+ * workgroup's wait; TC_STREAM_TEST_SKIP=m (tests) frames with (step + env) % m == 0 are left to the recover kernel;
+ * TC_CHUNK=n steps per chunk (0: chunks follow each other on the caller's stream, no overlap, no streaming),
+ * TC_ENV_GROUPED=0 one wavefront per env in every simulate launch (no overlap, no streaming),
+ * TC_FIRST_CHUNK_PER_ENV=0, TC_FRAME_STREAMS=1 (chunked form), TC_ENVG_MAP_LDS=0, TC_MULTI_SPLIT=0 a single fused launch
+ * in which the same wavefront simulates its env and rasterises each of its frames, TC_SEG_LDS=0 / TC_SEG_LDS_CAP=n draw
+ * lists through global memory only / beyond the first n segments, TC_FRAME_ORDER=0 frame workgroups in env order (default:
+ * the envs whose last frame had the longest draw list first, so that a dispatch ends with its cheapest frames),
  * TC_STEP_ORDER=n (tc_step: the envs are re-dealt to the workgroups every n-th step so that heavy and light frames share
  * a SIMD, default 8; 0 = workgroup w works on env w). */
 typedef struct {
@@ -298,17 +313,19 @@ typedef struct {
 int tc_step_multi(tc_env* env, const void* car_control, int32_t control_dtype, const int32_t* maneuver, int32_t n_steps,
                   uint32_t flags, const tc_rollout* rollout, void* stream);
 
-/* Sizes the scratch ring of K-step calls that render observations: TC_RING_SLOTS (3) chunks of min(max_chunk_steps,
- * 16 or TC_CHUNK) steps x N envs of pose rows (128 B) and draw lists (20 B x lane-line edges of the map; only a
- * frame's overflow beyond the LDS-resident head travels through them).  A call of ANY n_steps then runs in chunks
- * that fit the ring.  Re-allocating waits for the device first (an earlier launch may still read the old ring); a
- * request the current ring already covers returns at once.  max_chunk_steps < 1 is TC_E_INVALID. */
-int tc_env_reserve_steps(tc_env* env, int32_t max_chunk_steps);
+/* Sizes the scratch of K-step calls that render observations, for calls of up to max_call_steps steps: per (step, env)
+ * a pose row (128 B), a draw-list length and room for a draw list (20 B x lane-line edges of the map; only a frame's
+ * overflow beyond the LDS-resident head travels through it).  Streamed form: min(max_call_steps, 128) steps x N envs
+ * (cfg3: 22 MB per step); chunked form: a ring of TC_RING_SLOTS (3) chunks of min(max_call_steps, 16 or TC_CHUNK) steps.
+ * A call of ANY n_steps then runs in segments / chunks that fit.  Re-allocating waits for the device first (an earlier
+ * launch may still use the old arrays); a request the current scratch already covers returns at once.
+ * max_call_steps < 1 is TC_E_INVALID. */
+int tc_env_reserve_steps(tc_env* env, int32_t max_call_steps);
 
 /* What the library launches for a call of n_steps steps (1 = tc_step) with the current settings -- for benchmark
  * labels, not for control flow: fused = 1 when simulate + raster run as one kernel; kvar = register-cache variant of
  * the simulate stage (5, 8, 9, 13); steps_per_dispatch = steps one kernel dispatch of the call covers when every
- * step's frame goes to a rollout (a K-step call is issued as pipelined chunks: see tc_step_multi); name receives the
+ * step's frame goes to a rollout (the whole call when it is streamed, else a chunk: see tc_step_multi); name receives the
  * kernel symbols ("tc_step_kernel", "tc_envg_kernel+tc_frame_kernel", "tc_env_kernel+tc_raster_kernel", "tc_env_kernel"),
  * at most name_cap bytes including the terminator. */
 int tc_env_launch_info(const tc_env* env, uint32_t flags, int32_t n_steps, int32_t* fused, int32_t* kvar,
@@ -316,7 +333,7 @@ int tc_env_launch_info(const tc_env* env, uint32_t flags, int32_t n_steps, int32
 
 /* Workload descriptor for benchmark lines -- what the most recent frames drew: mean / max length of the frames' draw
  * lists (segments handed to cv2.polylines, camera.py:95-106) and the fraction of frames with none, over the N frames of
- * the last tc_step or the frames of the last (up to 3) chunks of the last tc_step_multi call.  Waits for the device. */
+ * the last tc_step or, of the last tc_step_multi call, the frames of its last (up to 48) steps.  Waits for the device. */
 int tc_env_draw_list_stats(tc_env* env, double* mean_segments, double* empty_frac, int32_t* max_segments, int64_t* frames);
 
 /* Renderer.render_camera_frame_{rgb,classes} alone (renderer.py:36-51): rasterise caller-provided segment lists

@@ -265,6 +265,36 @@ def test_first_step_multi_call_can_be_captured_into_a_graph():
     b.close()
 
 
+def test_prepared_call_is_step_multi_without_the_argument_checks():
+    """prepare_step_multi(): the call object re-issues tc_step_multi on the same tensors (contents changed in between)"""
+    n, K = 128, 12
+    a = make_env("simple_layout", "r64", "classes", n, autoreset=True)
+    b = make_env("simple_layout", "r64", "classes", n, autoreset=True)
+    a.reset(seed=11)
+    b.reset(seed=11)
+    cc, man = bench_actions(n, K, seed=1)
+    ra, rb = a.alloc_rollout(K, keys="all"), b.alloc_rollout(K, keys="all")
+    call = a.prepare_step_multi(cc, man, ra)
+    for rep in range(3):
+        c2, m2 = mixed_actions(n, K, seed=20 + rep)
+        cc.copy_(c2)
+        man.copy_(m2)
+        call()
+        b.step_multi(cc, man, rollout=rb)
+        torch.cuda.synchronize()
+        for k in ra:
+            x, y = ra[k], rb[k]
+            if x.dtype == torch.float64:
+                x, y = x.view(torch.int64), y.view(torch.int64)
+            assert torch.equal(x, y), (rep, k)
+    with pytest.raises(ValueError):
+        a.prepare_step_multi(cc[:, :5], man, ra)
+    a.close()
+    with pytest.raises(RuntimeError):
+        call()
+    b.close()
+
+
 @pytest.mark.parametrize("order,n", [("1", 4096), ("3", 2048), ("0", 2048)])
 def test_single_steps_with_cost_aware_env_order(order, n, monkeypatch):
     """tc_step deals the envs to its workgroups by the previous frames' draw-list lengths (tc_order_kernel: which envs

@@ -566,8 +566,14 @@ class TinyCarloVecEnv(gym.Env):
         int32, both on the device.  Bit-identical to K calls of `step_device`; self.state / self.out hold step K-1
         afterwards.  `rollout` (from `alloc_rollout`) receives every step's outputs; with rollout["obs"] the
         observations go there and self.out["obs"] is left untouched."""
-        if not self._was_reset:
-            raise RuntimeError("step_multi() before reset()")
+        self.prepare_step_multi(car_control, maneuver, rollout)()
+
+    def prepare_step_multi(self, car_control: torch.Tensor, maneuver: torch.Tensor,
+                           rollout: Optional[Dict[str, torch.Tensor]] = None) -> "PreparedStepMulti":
+        """Checks the arguments of a `step_multi` call and sizes the library's scratch for it once, and returns the call
+        as an object: `call()` then only enqueues it (one C call on the current stream) -- for loops that step the same
+        action / rollout tensors again and again (their CONTENTS may change between calls, the tensors may not), where
+        the argument checks of `step_multi` (tens of microseconds of Python) would be paid per call."""
         if car_control.dim() != 3 or tuple(car_control.shape[1:]) != (self.num_envs, 2):
             raise ValueError(f"car_control must be [K, {self.num_envs}, 2], got {tuple(car_control.shape)}")
         K = int(car_control.shape[0])
@@ -579,11 +585,6 @@ class TinyCarloVecEnv(gym.Env):
             raise ValueError("car_control must be float32|float64 and maneuver int32")
         if not (car_control.is_contiguous() and maneuver.is_contiguous()):
             raise ValueError("step_multi takes contiguous tensors")
-        self._note_fresh()
-        dbg = gym_getenv("DEBUG")
-        if dbg:
-            t_dbg = time.perf_counter()
-            self.profile(1)
         r = nat.Rollout()
         if rollout:
             want = self._shape_cache.get(K)
@@ -596,16 +597,9 @@ class TinyCarloVecEnv(gym.Env):
                 if t.dtype != dt_ or tuple(t.shape) != shp or t.device != self.device or not t.is_contiguous():
                     raise ValueError(f"rollout[{k!r}] must be a contiguous {dt_} tensor of shape {shp} on {self.device}")
                 setattr(r, k, t.data_ptr())
-        dt = nat.F64 if car_control.dtype == torch.float64 else nat.F32
         if K > 1 and not (self.no_observation and self.render_mode is None):
-            self.reserve_steps(K)  # (no-op once the ring covers K: the call below never allocates)
-        with torch.cuda.device(self.device):
-            nat.check(nat.lib().tc_step_multi(self._h, car_control.data_ptr(), dt, maneuver.data_ptr(), K, self._flags(),
-                                              C.byref(r) if rollout else None, self._stream()), "tc_step_multi")
-        self._keep = (car_control, maneuver, rollout)
-        self._step_serial += 1
-        if dbg:
-            self._debug_print(f"step_multi[{K}]", t_dbg)
+            self.reserve_steps(K)  # (no-op once the scratch covers K: the call itself never allocates)
+        return PreparedStepMulti(self, car_control, maneuver, rollout, r, K)
 
     def launch_info(self, n_steps: int = 1) -> Dict[str, Any]:
         """What a call of n_steps steps launches with the current settings (tc_env_launch_info): for benchmark labels."""
@@ -736,3 +730,42 @@ class TinyCarloVecEnv(gym.Env):
                 return {k: cv(x) for k, x in v.items()} if isinstance(v, dict) else v.cpu().numpy()
             return {k: cv(info[k]) for k in info}
         return info
+
+
+class PreparedStepMulti:
+    """A checked `step_multi` call (`TinyCarloVecEnv.prepare_step_multi`): calling it enqueues tc_step_multi with the
+    tensors it was prepared with, on the stream current at that moment."""
+
+    __slots__ = ("env", "_keep", "_args", "_rollout_ref", "K")
+
+    def __init__(self, env, car_control, maneuver, rollout, r, K):
+        self.env = env
+        self.K = K
+        self._keep = (car_control, maneuver, rollout)   # the tensors stay alive as long as the call can be issued
+        self._rollout_ref = r
+        dt = nat.F64 if car_control.dtype == torch.float64 else nat.F32
+        self._args = (car_control.data_ptr(), dt, maneuver.data_ptr(), K, C.byref(r) if rollout else None)
+
+    def __call__(self) -> None:
+        env = self.env
+        if not env._was_reset:
+            raise RuntimeError("step_multi() before reset()")
+        if env._h is None:
+            raise RuntimeError("the env was closed")
+        env._note_fresh()
+        dbg = gym_getenv("DEBUG")
+        if dbg:
+            t_dbg = time.perf_counter()
+            env.profile(1)
+        a = self._args
+        if torch.cuda.current_device() == env.device.index:
+            rc = nat.lib().tc_step_multi(env._h, a[0], a[1], a[2], a[3], env._flags(), a[4], env._stream())
+        else:
+            with torch.cuda.device(env.device):
+                rc = nat.lib().tc_step_multi(env._h, a[0], a[1], a[2], a[3], env._flags(), a[4], env._stream())
+        if rc != 0:
+            nat.check(rc, "tc_step_multi")
+        env._keep = self._keep
+        env._step_serial += 1
+        if dbg:
+            env._debug_print(f"step_multi[{self.K}]", t_dbg)
