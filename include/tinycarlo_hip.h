@@ -265,9 +265,9 @@ int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const i
  *     entries validates itself: a row is "not written yet" while any entry holds an all-ones NaN, and the frame
  *     workgroup puts that pattern back when it is done).  Only the call's first step is exposed, and the chip drains
  *     once per call instead of once per chunk.  Around the two launches, on the internal stream: tc_order_kernel
- *     (heaviest frames first, see TC_FRAME_ORDER), tc_gate_kernel (one wavefront: holds the frame launch back until
+ *     (heaviest frames first, see TC_FRAME_ORDER), tc_gate_kernel, one wavefront that holds the frame launch back until
  *     every simulate workgroup has started, so the frame workgroups can fill the chip without keeping their producers
- *     off it) and, behind the simulate launch, tc_frame_recover_kernel.  EVERY wait on the device is bounded
+ *     off it, and, behind the simulate launch, tc_frame_recover_kernel.  EVERY wait on the device is bounded
  *     (TC_STREAM_WAIT_US, default 5000): a frame workgroup whose wait runs out marks its frame skipped, tells the others
  *     to stop waiting and leaves, and the recover kernel -- one workgroup per env, normally one look at the call's
  *     rows and out -- draws the skipped frames from the then complete rows.  The result therefore never depends on
