@@ -666,12 +666,19 @@ __device__ inline void r_hline_2w(const Ras& r, int y, int xl, int xr) {
 // Circle(center, rad, fill) is the union of centred spans, so per row only the widest one matters.
 // A centre more than 2^20 pixels away cannot reach a frame of at most 16384 x 16384 with rad < 32, whatever Circle()'s
 // 64-bit arithmetic makes of it; everything nearer is plain 32-bit arithmetic.
+// hw[] is indexed by the row offset, which is the same in every lane: read with scalar loads (a vector load here -- it
+// used to be one, from the kernarg segment -- makes the wavefront wait for every store it has in flight: vector memory
+// operations retire in order).  The table is 4-byte aligned (RCam) and constant for the kernel's lifetime.
+__device__ __forceinline__ int r_cap_hw(const unsigned char* hw, int ady) {
+  const unsigned int w = ((const __attribute__((address_space(4))) unsigned int*)(unsigned long long)hw)[ady >> 2];
+  return (int)((w >> ((ady & 3) << 3)) & 255u);
+}
 __device__ inline void r_cap(const Ras& r, int cx, int cy, int rad, const unsigned char* hw, unsigned int hw4) {
   const bool near = (unsigned)cx + (1u << 20) <= (2u << 20) && (unsigned)cy + (1u << 20) <= (2u << 20);
   if (rad <= 15) {  // spans of at most 31 pixels
     for (int dy = -rad; dy <= rad; dy++) {
       const int ady = dy < 0 ? -dy : dy;
-      const int h = rad <= 3 ? (int)((hw4 >> (8 * ady)) & 255u) : (int)hw[ady];
+      const int h = rad <= 3 ? (int)((hw4 >> (8 * ady)) & 255u) : r_cap_hw(hw, ady);
       const int y = cy + dy, xl = cx - h, xr = cx + h;
       const bool ok = near && y >= 0 && y < r.H && xr >= 0 && xl < r.W;
       r_hline_2w(r, ok ? y : -1, ok ? xl : 1, ok ? xr : 0);  // (at most 31 pixels: two words at most)
@@ -680,7 +687,7 @@ __device__ inline void r_cap(const Ras& r, int cx, int cy, int rad, const unsign
   }
   for (int dy = -rad; dy <= rad; dy++) {
     const int ady = dy < 0 ? -dy : dy;
-    const int h = (int)hw[ady];
+    const int h = r_cap_hw(hw, ady);
     const int y = cy + dy, xl = cx - h, xr = cx + h;
     const bool ok = near && y >= 0 && y < r.H && xr >= 0 && xl < r.W;
     r_hline(r, ok ? y : -1, ok ? (xl < 0 ? 0 : xl) : 1, ok ? (xr > r.W - 1 ? r.W - 1 : xr) : 0);

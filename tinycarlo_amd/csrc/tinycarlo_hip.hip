@@ -1466,12 +1466,31 @@ struct RArgs {
   unsigned long long noise_seed;
   const unsigned int* noise_step;
   int seg_lds_off, seg_lds_cap;  // see KArgs
+  unsigned int colors_packed[16];  // colors[c] as r | g << 8 | b << 16: read with scalar loads (uniform class index)
 };
 
 #ifndef TC_RASTER_WAVES
 #define TC_RASTER_WAVES 4
 #endif
-template <bool THICK, int FMT>
+// LDSONLY (tc_frame_kernel): the stage reads draw-list entries from LDS only, and its common path contains no vector load
+// at all.  That matters beyond the loads themselves: vector memory operations retire in issue order, and the compiler
+// guards a load that MAY have been issued (the k >= seg_lds_cap branch of seg_get) with s_waitcnt vmcnt(0) at the join --
+// which, executed by a wavefront that took the LDS branch, waits for nothing but the wavefront's own earlier STORES: the
+// zero planes stored at the head of the stage, the previous band's pixels.  Without the branch the stores drain behind
+// the raster work (cfg5: band b's 38 KB land while band b+1 is rasterised).
+//   A frame whose list outgrew the LDS head (nseg_in > a.seg_lds_cap: the caller has then put the WHOLE list into the
+// global array, head included) is rasterised batch by batch all the same: each batch of RB entries is first copied from
+// the global list to the start of the LDS region -- loads and their wait inside a branch the common path never enters.
+// Flow control of a banded frame's stores (cfg5: 19 bands of 38 KB): before a band's stores are issued, the stores of the
+// band before it must have landed.  With no wait at all a wavefront runs up to 63 store instructions ahead and the chip
+// as a whole writes SLOWER (cfg5, stores only: 2.81 ms per dispatch against 2.62); with the wait at the head of the band
+// (where the compiler used to put one) the raster work of band b+1 cannot overlap the stores of band b (3.36 ms -> see
+// DESIGN.md 6); here the raster work overlaps and at most one band is in flight.
+#ifndef TC_BAND_VMCNT
+#define TC_BAND_VMCNT 0
+#endif
+#define TC_BAND_THROTTLE() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TC_BAND_VMCNT) : "memory")
+template <bool THICK, int FMT, bool LDSONLY = false>
 __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem, int env, unsigned char* obs_base,
                                             const int tid, const size_t seg_slot0, const int nseg_in,
                                             const unsigned int used_in, const int frame_row) {
@@ -1486,9 +1505,22 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
     int v[5];
     __device__ __forceinline__ int operator[](int i) const { return v[i]; }
   };
+  // LDSONLY: entry k sits at LDS slot k - lds_base (lds_base = 0, or the first entry of the batch just copied in)
+  int lds_base = 0;
+  const bool refill = LDSONLY && nseg_in > seg_lds_cap;  // (wave-uniform)
+  const int rb_step = (refill && seg_lds_cap < RB) ? seg_lds_cap : RB;  // batch size (the LDS region holds >= 8 entries: tc_env_create)
+  auto seg_refill = [&](int base, int nb) {  // global entries [base, base + nb) -> LDS slots [0, nb); nb <= rb_step <= seg_lds_cap
+    lds_sync();  // the batch before has been read
+    for (int i = threadIdx.x; i < 5 * nb; i += TC_NT) seg_lds[i] = segg[5 * base + i];
+    lds_base = base;
+    lds_sync();
+  };
   auto seg_get = [&](int k) {
     SegV r;
-    if (k < seg_lds_cap) {
+    if (LDSONLY) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) r.v[i] = seg_lds[5 * (k - lds_base) + i];
+    } else if (k < seg_lds_cap) {
 #pragma unroll
       for (int i = 0; i < 5; i++) r.v[i] = seg_lds[5 * k + i];
     } else {
@@ -1497,13 +1529,13 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
     }
     return r;
   };
-  auto seg_layer = [&](int k) { return k < seg_lds_cap ? seg_lds[5 * k] : segg[5 * k]; };
+  auto seg_layer = [&](int k) { return LDSONLY ? seg_lds[5 * (k - lds_base)] : k < seg_lds_cap ? seg_lds[5 * k] : segg[5 * k]; };
   // draw-list length and the layers that have a segment in this frame (wave-uniform): handed over in registers by the
   // camera stage of the same wavefront, or read back when this is a launch of its own (nseg_in < 0)
   int nseg = nseg_in;
   unsigned int used_layers = used_in;
   TSTAMP(8);
-  if (nseg_in < 0) {
+  if (!LDSONLY && nseg_in < 0) {
     nseg = a.seg_n[seg_slot0 + env];
     used_layers = 0;
     for (int k = tid; k < nseg; k += TC_NT) used_layers |= 1u << segg[5 * k];
@@ -1558,7 +1590,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
       // is all zeros whatever the format (and whatever the noise blobs copy or erase), so it is written as a plain
       // stream of 16-byte zero stores: no bit-planes to clear, nothing to scan, and no wait for the zeros to land before
       // pixel stores that never come.
-      bool touched = false;
+      bool touched = refill;  // (a list that is not in LDS as a whole is not worth a pass of its own)
       const long long mg = (long long)cam.thickness + 2;  // ThickLine paints within thickness / 2 + 1 rows of the segment
       for (int k0 = 0; k0 < nseg && !touched; k0 += TC_NT) {
         bool t = false;
@@ -1572,6 +1604,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
       if (!touched && DBG_ON(a.flags, DBG_SKIP_STORE)) continue;
       if (!touched) {
         const uint4 z = make_uint4(0, 0, 0, 0);
+        TC_BAND_THROTTLE();
         if (FMT == TC_FMT_CLASSES) {
           const int per_plane = rows * (W >> 4);
           for (int c = 0; c < C; c++) {
@@ -1605,21 +1638,26 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
     const int plane = cam.band_rows * wpr;
     if (DBG_ON(a.flags, DBG_SKIP_RASTER)) {
     } else if (!THICK) {
-      for (int k = tid; k < nseg; k += TC_NT) {
-        const SegV sg = seg_get(k);
-        r.bits = bits + sg[0] * plane;
-        r_line_bresenham(r, sg[1], sg[2], sg[3], sg[4]);  // ThickLine with thickness <= 1 is a plain Line()
+      for (int base = 0; base < nseg; base += refill ? rb_step : nseg) {
+        const int nb = refill ? (nseg - base < rb_step ? nseg - base : rb_step) : nseg;
+        if (refill) seg_refill(base, nb);
+        for (int k = base + tid; k < base + nb; k += TC_NT) {
+          const SegV sg = seg_get(k);
+          r.bits = bits + sg[0] * plane;
+          r_line_bresenham(r, sg[1], sg[2], sg[3], sg[4]);  // ThickLine with thickness <= 1 is a plain Line()
+        }
       }
     } else {
       // ThickLine = FillConvexPoly(quad) [4 Line2 outline edges + scanline fill] + 2 round caps.
       // Segments are taken RB at a time; their pixel work is cut into small uniform items that are dealt
       // to the 64 lanes through prefix sums, so one long line does not serialise the wave.
-      for (int base = 0; base < nseg; base += RB) {
+      for (int base = 0; base < nseg; base += rb_step) {
         // (the loops usually run once: arguments are re-read inside them instead of being hoisted in front and held --
         // or spilled -- across the whole stage)
         const RArgs& a = kernarg_again(a0);
         const RCam& cam = a.cam;
-        const int nb = nseg - base < RB ? nseg - base : RB;
+        const int nb = nseg - base < rb_step ? nseg - base : rb_step;
+        if (refill) seg_refill(base, nb);
 #ifdef TC_TIMING_LDS
         if (cam.n_bands >= 0) TSTAMP(27);  // first value of the re-read argument block has arrived
 #endif
@@ -1849,6 +1887,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
     TSTAMP(12);
     const RArgs& a = kernarg_again(a0);
     const RCam& cam = a.cam;
+    if (cam.n_bands > 1) TC_BAND_THROTTLE();
     if (DBG_ON(a.flags, DBG_SKIP_STORE)) {
     } else if (FMT == TC_FMT_CLASSES) {
       if ((W & 15) == 0) {
@@ -1932,24 +1971,32 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
           const uint4 z = make_uint4(0, 0, 0, 0);
           for (int q = tid; q < n16; q += TC_NT) dst[q] = z;
         }
+        // Class by class, highest first; a class paints the pixels it covers that no higher class covers.  The colour of a
+        // class is then ONE value for the whole wavefront, fetched with a scalar load.  (Looked up per pixel --
+        // colors[top][k] with `top` differing between lanes -- it was a vector load from the kernarg segment, and vector
+        // memory operations retire in order: the wavefront sat out the round trip of this band's zero stores at every
+        // such load, which is why raster and store time of cfg5 added up instead of overlapping -- ablation)
         const int nw = rows * wpr;
-        for (int q = tid; q < nw; q += TC_NT) {
-          unsigned int any = 0;
-          for (int c = 0; c < C; c++) any |= bits[c * cam.band_rows * wpr + q];
-          if (any == 0) continue;
-          const int yy = q / wpr, xw = (q - yy * wpr) << 5;
-          unsigned char* row = out + ((size_t)(y0 + yy) * W + xw) * 3;
-          while (any) {
-            const int bpos = __ffs(any) - 1;
-            any &= any - 1;
-            int top = 0;
-            for (int c = 1; c < C; c++)
-              if ((bits[c * cam.band_rows * wpr + q] >> bpos) & 1u) top = c;
-            // `any` has the bit, so some plane has it; plane 0 is the default when no higher one does
-            unsigned char* o = row + bpos * 3;
-            o[0] = a.colors[top][0];
-            o[1] = a.colors[top][1];
-            o[2] = a.colors[top][2];
+        const int pstride = cam.band_rows * wpr;
+        const __attribute__((address_space(4))) unsigned int* pk =
+            (const __attribute__((address_space(4))) unsigned int*)(unsigned long long)&a.colors_packed[0];
+        for (int c = C - 1; c >= 0; c--) {
+          const unsigned int col = pk[c];
+          const unsigned char c0 = (unsigned char)col, c1 = (unsigned char)(col >> 8), c2 = (unsigned char)(col >> 16);
+          for (int q = tid; q < nw; q += TC_NT) {
+            unsigned int mine = bits[c * pstride + q];
+            if (mine == 0) continue;
+            for (int h = c + 1; h < C; h++) mine &= ~bits[h * pstride + q];
+            const int yy = q / wpr, xw = (q - yy * wpr) << 5;
+            unsigned char* row = out + ((size_t)(y0 + yy) * W + xw) * 3;
+            while (mine) {
+              const int bpos = __ffs(mine) - 1;
+              mine &= mine - 1;
+              unsigned char* o = row + bpos * 3;
+              o[0] = c0;
+              o[1] = c1;
+              o[2] = c2;
+            }
           }
         }
       } else if ((W & 3) == 0) {
@@ -2713,28 +2760,24 @@ __device__ __forceinline__ const FrameArgs& frame_args() {
   asm volatile("" : "+s"(p));
   return *(const FrameArgs*)(FrameArgsConst)p;
 }
-// One frame: `rowy` is the frame's row in the launch (its step), `env` its env.
-template <int K, bool THICK, int FMT>
-__device__ __forceinline__ void frame_one(unsigned char* smem, const int env, const int rowy) {
+// The pose row of frame (slot0 + env).  In a streamed call (fa.gate) the row may not exist yet: lanes 0..11 read one entry
+// each with device-scope loads (sc1: neither this CU's caches nor this XCD's L2 may answer with an older copy; the scalar
+// cache is out of the question) until none holds TC_POSE_EMPTY; the values then move to scalar registers.  Rows are
+// dispatched in step order and the simulate launch is resident before the frame kernel starts (tc_gate_kernel), so the
+// wait ends -- but nothing relies on that: a wait that outlasts gate_ticks marks the frame skipped, tells the others and
+// returns false, and tc_frame_recover_kernel, behind the simulate launch, draws the frame.  `wait` false: the row is known
+// to be there (gate 2, or read before by this workgroup) -- one read.
+__device__ __forceinline__ bool frame_pose(const size_t slot0, const int env, const int row, const bool wait, double* pose) {
   const FrameArgs& fa = frame_args();
   const int tid = threadIdx.x;
-  const int row = fa.r.seg_row0 + rowy;
-  const size_t slot0 = (size_t)row * fa.a.N;
-  double pose[12];
   if (fa.gate) {
-    // Streamed call: the row may not exist yet.  Lanes 0..11 read one entry each with device-scope loads (sc1: neither
-    // this CU's caches nor this XCD's L2 may answer with an older copy; the scalar cache is out of the question) until
-    // none holds TC_POSE_EMPTY; the values then move to scalar registers.  Rows are dispatched in step order and the
-    // simulate launch is resident before this kernel starts (tc_gate_kernel), so the wait ends -- but nothing here relies
-    // on that: a wait that outlasts gate_ticks marks the frame skipped, tells the others and leaves, and
-    // tc_frame_recover_kernel, behind the simulate launch, draws it.
     unsigned long long* prow = (unsigned long long*)(fa.pose_rows + (slot0 + env) * TC_POSE_ROW);
     unsigned long long v = 0;
-    bool give_up = fa.gate == 1 && fa.gate_test > 0 && (row + env) % fa.gate_test == 0;
+    bool give_up = wait && fa.gate == 1 && fa.gate_test > 0 && (row + env) % fa.gate_test == 0;
     long long t0 = 0;
     while (!give_up) {
       v = tid < 12 ? __hip_atomic_load(prow + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-      if (__ballot(v == TC_POSE_EMPTY) == 0 || fa.gate == 2) break;
+      if (__ballot(v == TC_POSE_EMPTY) == 0 || fa.gate == 2 || !wait) break;
       const long long now = wall_clock64();
       if (t0 == 0) t0 = now;
       if (now - t0 > fa.gate_ticks || __hip_atomic_load(fa.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
@@ -2747,7 +2790,7 @@ __device__ __forceinline__ void frame_one(unsigned char* smem, const int env, co
         if (t0 != 0) __hip_atomic_store(fa.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (not the test's skips)
         fa.a.seg_n[slot0 + env] = TC_FRAME_SKIPPED;
       }
-      return;
+      return false;
     }
     const unsigned int vlo = (unsigned int)v, vhi = (unsigned int)(v >> 32);
 #pragma unroll
@@ -2757,34 +2800,59 @@ __device__ __forceinline__ void frame_one(unsigned char* smem, const int env, co
       pose[i] = __longlong_as_double((long long)q);
     }
   } else {
-    // the pose row the simulate launch wrote for this (step, env): one address for the whole wavefront, read through the
-    // scalar cache (written by an earlier launch: complete and visible before this kernel started)
+    // written by an earlier launch, complete and visible before this kernel started: one address for the whole wavefront,
+    // read through the scalar cache
     const __attribute__((address_space(4))) double* pr =
         (const __attribute__((address_space(4))) double*)(unsigned long long)(fa.pose_rows + (slot0 + env) * TC_POSE_ROW);
 #pragma unroll
     for (int i = 0; i < 12; i++) pose[i] = pr[i];
   }
-  MapCache<K> mc;
+  return true;
+}
+
+// One frame: `rowy` is the frame's row in the launch (its step), `env` its env.
+// HOT (tc_frame_kernel): the raster stage in its LDS-only form (see raster_body); !HOT (the recover kernel): the generic form.
+template <int K, bool THICK, int FMT, bool HOT>
+__device__ __forceinline__ void frame_one(unsigned char* smem, const int env, const int rowy) {
+  const int tid = threadIdx.x;
   int nseg;
   unsigned int used;
-  TSTAMP_CLEAR();
-  TSTAMP(3);
-  TSTAMP_REAL(30);
-  cam_body<K>(fa.a, smem, env, pose, mc, false, tid, row, nseg, used, false);
-
-  if (nseg > fa.a.seg_lds_cap)
-    __syncthreads();  // draw-list entries that went through global memory are visible to this wavefront (vmcnt(0) + barrier)
-  else
-    lds_sync();
+  {
+    const FrameArgs& fa = frame_args();
+    const int row = fa.r.seg_row0 + rowy;
+    const size_t slot0 = (size_t)row * fa.a.N;
+    double pose[12];
+    if (!frame_pose(slot0, env, row, true, pose)) return;
+    MapCache<K> mc;
+    TSTAMP_CLEAR();
+    TSTAMP(3);
+    TSTAMP_REAL(30);
+    cam_body<K>(fa.a, smem, env, pose, mc, false, tid, row, nseg, used, false);
+  }
   const FrameArgs& fr = frame_args();
-  raster_body<THICK, FMT>(fr.r, smem, env, fr.r.obs + (size_t)rowy * fr.r.obs_row_stride, tid, slot0, nseg, used,
-                          fr.r.noise_row0 + rowy);
+  const size_t slot0 = (size_t)(fr.r.seg_row0 + rowy) * fr.a.N;
+  if (__builtin_expect(nseg > fr.a.seg_lds_cap, 0)) {  // (wave-uniform; cfg3: more than 56 segments)
+    if (HOT) {
+      // the list outgrew the LDS head: its tail is in the global array already, the head follows, and the raster stage
+      // takes the whole list from there batch by batch
+      lds_sync();
+      const LdsIntPtr sl = (LdsIntPtr)(smem + fr.a.seg_lds_off);
+      int* sg = fr.a.seg_g + (slot0 + env) * fr.a.seg_cap * 5;
+      for (int i = tid; i < 5 * fr.a.seg_lds_cap; i += TC_NT) sg[i] = sl[i];
+    }
+    __syncthreads();  // draw-list entries that went through global memory are visible to this wavefront (vmcnt(0) + barrier)
+  } else {
+    lds_sync();
+  }
+  raster_body<THICK, FMT, HOT>(fr.r, smem, env, fr.r.obs + (size_t)rowy * fr.r.obs_row_stride, tid, slot0, nseg, used,
+                               fr.r.noise_row0 + rowy);
   {
     const FrameArgs& fe = frame_args();
-    if (tid == 0) fe.a.seg_n[slot0 + env] = nseg;  // workload statistics, the next dispatch's order, "drawn" for the recover pass
+    const size_t slot = (size_t)(fe.r.seg_row0 + rowy) * fe.a.N + env;
+    if (tid == 0) fe.a.seg_n[slot] = nseg;  // workload statistics, the next dispatch's order, "drawn" for the recover pass
     // a streamed call's row goes back to "not written yet" for the next call (which starts behind this kernel)
     if (fe.gate && tid < 12)
-      __hip_atomic_store((unsigned long long*)(fe.pose_rows + (slot0 + env) * TC_POSE_ROW) + tid, TC_POSE_EMPTY, __ATOMIC_RELAXED,
+      __hip_atomic_store((unsigned long long*)(fe.pose_rows + slot * TC_POSE_ROW) + tid, TC_POSE_EMPTY, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
   }
   TSTAMP_DUMP(env);
@@ -2797,12 +2865,13 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame
   if ((int)blockIdx.x >= fa.a.N) return;
   const int env = fa.order ? uni_i(((const __attribute__((address_space(4))) int*)(unsigned long long)fa.order)[blockIdx.x])
                            : fa.a.env0 + (int)blockIdx.x;
-  frame_one<K, THICK, FMT>(smem, env, (int)blockIdx.y);
+  frame_one<K, THICK, FMT, true>(smem, env, (int)blockIdx.y);
 }
 
 // The pass behind a streamed call's simulate launch: one workgroup per env looks through the call's rows for frames a
-// gated workgroup gave up on (normally none: one strided read per row block and out) and draws them itself, one after
-// the other, with gate = 2 (the row is there: read once, no waiting).  Workgroup 0 resets the call's two words.
+// gated workgroup gave up on (TC_FRAME_SKIPPED; normally none: one strided read per row block and out) and draws them
+// itself, one after the other, with gate = 2 (the row is there: read once, no waiting) and the generic form of both
+// stages.  Workgroup 0 resets the call's two words.
 // Never on the hot path, so what the step loop around a ~10 k-instruction body costs in registers does not matter.
 template <int K, bool THICK, int FMT>
 __global__ __launch_bounds__(TC_NT) void tc_frame_recover_kernel(FrameArgs fa_unused) {
@@ -2810,18 +2879,18 @@ __global__ __launch_bounds__(TC_NT) void tc_frame_recover_kernel(FrameArgs fa_un
   const FrameArgs& fa = frame_args();
   const int env = (int)blockIdx.x, tid = threadIdx.x;
   if (env >= fa.a.N) return;
-  if (env == 0 && tid == 0) {
+  if (fa.gate && env == 0 && tid == 0) {
     __hip_atomic_store(fa.abort_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(fa.resident, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const int rows = fa.recover_rows;
-  bool any = false;
-  for (int r = tid; r < rows; r += TC_NT) any |= ((const volatile int*)fa.a.seg_n)[(size_t)(fa.r.seg_row0 + r) * fa.a.N + env] == TC_FRAME_SKIPPED;
+  bool any = false;  // (TC_FRAME_SKIPPED: the only negative length)
+  for (int r = tid; r < rows; r += TC_NT) any |= ((const volatile int*)fa.a.seg_n)[(size_t)(fa.r.seg_row0 + r) * fa.a.N + env] < 0;
   if (__ballot(any) == 0) return;
   for (int r = 0; r < rows; r++) {
     const FrameArgs& fb = frame_args();
-    if (uni_i(((const volatile int*)fb.a.seg_n)[(size_t)(fb.r.seg_row0 + r) * fb.a.N + env]) != TC_FRAME_SKIPPED) continue;
-    frame_one<K, THICK, FMT>(smem, env, r);
+    if (uni_i(((const volatile int*)fb.a.seg_n)[(size_t)(fb.r.seg_row0 + r) * fb.a.N + env]) >= 0) continue;
+    frame_one<K, THICK, FMT, false>(smem, env, r);
     __syncthreads();  // the next frame reuses the LDS
   }
 }
@@ -2945,11 +3014,18 @@ __global__ __launch_bounds__(64) void tc_gate_kernel(const unsigned int* residen
 
 typedef void (*fused_kern_t)(StepArgs);
 // TC_DEV_FAST (make dev): only the K = 5 / thick / classes variants are instantiated -- a compile of seconds instead of
-// minutes for kernel work on cfg3.  Never shipped: the default build has no such macro.
+// minutes for kernel work on cfg3 (make dev DEVK=9 DEVFMT=TC_FMT_RGB: the variants of cfg5; DEVK=9 alone: cfg4).  Never
+// shipped: the default build has no such macro.
+#ifndef TC_DEV_KV
+#define TC_DEV_KV 5
+#endif
+#ifndef TC_DEV_FMTV
+#define TC_DEV_FMTV TC_FMT_CLASSES
+#endif
 template <int K>
 static fused_kern_t pick_fused(bool thick, bool cls) {
 #ifdef TC_DEV_FAST
-  return tc_step_kernel<5, true, TC_FMT_CLASSES>;
+  return tc_step_kernel<TC_DEV_KV, true, TC_DEV_FMTV>;
 #else
   return thick ? (cls ? tc_step_kernel<K, true, TC_FMT_CLASSES> : tc_step_kernel<K, true, TC_FMT_RGB>)
                : (cls ? tc_step_kernel<K, false, TC_FMT_CLASSES> : tc_step_kernel<K, false, TC_FMT_RGB>);
@@ -2960,7 +3036,7 @@ typedef void (*frame_kern_t)(FrameArgs);
 template <int K>
 static frame_kern_t pick_frame(bool thick, bool cls) {
 #ifdef TC_DEV_FAST
-  return tc_frame_kernel<5, true, TC_FMT_CLASSES>;
+  return tc_frame_kernel<TC_DEV_KV, true, TC_DEV_FMTV>;
 #else
   return thick ? (cls ? tc_frame_kernel<K, true, TC_FMT_CLASSES> : tc_frame_kernel<K, true, TC_FMT_RGB>)
                : (cls ? tc_frame_kernel<K, false, TC_FMT_CLASSES> : tc_frame_kernel<K, false, TC_FMT_RGB>);
@@ -2970,7 +3046,7 @@ static frame_kern_t pick_frame(bool thick, bool cls) {
 template <int K>
 static frame_kern_t pick_recover(bool thick, bool cls) {
 #ifdef TC_DEV_FAST
-  return tc_frame_recover_kernel<5, true, TC_FMT_CLASSES>;
+  return tc_frame_recover_kernel<TC_DEV_KV, true, TC_DEV_FMTV>;
 #else
   return thick ? (cls ? tc_frame_recover_kernel<K, true, TC_FMT_CLASSES> : tc_frame_recover_kernel<K, true, TC_FMT_RGB>)
                : (cls ? tc_frame_recover_kernel<K, false, TC_FMT_CLASSES> : tc_frame_recover_kernel<K, false, TC_FMT_RGB>);
@@ -3051,6 +3127,7 @@ struct tc_env {
   int order_every, order_calls;
   int seg_lds_limit;  // TC_SEG_LDS_CAP
   int frame_lds, seg_lds_off, seg_lds_cap;  // tc_frame_kernel: LDS bytes per workgroup, draw-list region (see KArgs)
+  int frame_seg_cap;  // tc_frame_kernel's own capacity: seg_lds_cap, but never below 8 (its raster stage reads the list from LDS only)
   int frame_streams;  // short K-step calls: frame launches of consecutive chunks alternate between two streams (TC_FRAME_STREAMS)
   int prof_piped[TC_PROF_RING];
   int envg_map_lds; // tc_envg_kernel keeps the edge records in LDS when they fit (TC_ENVG_MAP_LDS=0: always from global)
@@ -3521,6 +3598,18 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
       if (v >= 0) e->seg_lds_limit = v;
       if (e->seg_lds_cap > e->seg_lds_limit) e->seg_lds_cap = e->seg_lds_limit;
     }
+    // tc_frame_kernel reads draw lists from LDS only (longer ones batch by batch through it): it keeps a region of at least
+    // 8 entries whatever the switches above say (they still rule tc_step_kernel, which has the generic form)
+    e->frame_seg_cap = e->seg_lds_cap;
+    if (e->frame_seg_cap < 8) {
+      e->frame_seg_cap = 8;
+      if (e->frame_lds < e->seg_lds_off + 8 * 20) e->frame_lds = e->seg_lds_off + 8 * 20;
+    }
+#ifdef TC_ABLATE
+    if (getenv("TC_PRINT_LDS"))
+      fprintf(stderr, "tc_env_create: lds.total %d off_live %d frame_lds %d seg_lds_cap %d r_lds %d band_rows %d n_bands %d\n", (int)L.total,
+              (int)L.off_live, e->frame_lds, e->seg_lds_cap, e->r_lds, e->k.cam.band_rows, e->k.cam.n_bands);
+#endif
 #ifdef TC_EXPERIMENT
     // occupancy experiments (make dev-exp, never shipped): unused LDS bytes per frame workgroup -> fewer workgroups per CU
     if (const char* pd = getenv("TC_LDS_PAD")) e->frame_lds += atoi(pd);
@@ -3965,6 +4054,7 @@ static RArgs make_rargs(tc_env* e, const int* seg_g, const int* seg_n, int seg_c
   }
   r.cam.cap_hw4 = r.cam.cap_hw[0] | (r.cam.cap_hw[1] << 8) | (r.cam.cap_hw[2] << 16) | ((unsigned)r.cam.cap_hw[3] << 24);
   memcpy(r.colors, e->k.m.colors, sizeof(r.colors));
+  for (int c = 0; c < 16; c++) r.colors_packed[c] = r.colors[c][0] | (r.colors[c][1] << 8) | ((unsigned)r.colors[c][2] << 16);
   r.seg_g = seg_g;
   r.seg_n = seg_n;
   r.seg_cap = seg_cap;
@@ -3997,7 +4087,7 @@ static int launch_raster(tc_env* e, const int* seg_g, const int* seg_n, int seg_
   RArgs r = make_rargs(e, seg_g, seg_n, seg_cap, mask, flags, env0, obs, with_noise);
   if (count < 0) count = e->k.N;
 #ifdef TC_DEV_FAST
-  auto kern = tc_raster_kernel<true, TC_FMT_CLASSES>;
+  auto kern = tc_raster_kernel<true, TC_DEV_FMTV>;
 #else
   const bool thick = r.cam.thickness > 1, cls = r.cam.format == TC_FMT_CLASSES;
   auto kern = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
@@ -4079,13 +4169,13 @@ static int reserve_stream(tc_env* e, int max_call_steps) {
   return TC_OK;
 }
 
-extern "C" int tc_env_reserve_steps(tc_env* e, int32_t max_chunk_steps) {
-  if (!e || max_chunk_steps < 1) return TC_E_INVALID;
+extern "C" int tc_env_reserve_steps(tc_env* e, int32_t max_call_steps) {
+  if (!e || max_call_steps < 1) return TC_E_INVALID;
   if (e->stream && e->env_grouped && e->pipe) {
-    int rc = reserve_stream(e, max_chunk_steps);
+    int rc = reserve_stream(e, max_call_steps);
     if (rc != TC_OK) return rc;
   }
-  int rows = max_chunk_steps < e->chunk ? max_chunk_steps : e->chunk;
+  int rows = max_call_steps < e->chunk ? max_call_steps : e->chunk;
   if (rows < 2) rows = 2;  // (a pipelined call never uses chunks of fewer than 2 steps)
   if (e->ring_rows >= rows) return TC_OK;
   HIP_TRY(hipDeviceSynchronize());  // earlier launches may still read the old ring
@@ -4140,8 +4230,8 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   const int kv = e->kvar;
   // simulate stage alone, with or without the camera stage compiled in (without: fewer registers, half the code)
 #ifdef TC_DEV_FAST
-  auto kern = tc_env_kernel<5, true>;
-  auto kern_nocam = tc_env_kernel<5, false>;
+  auto kern = tc_env_kernel<TC_DEV_KV, true>;
+  auto kern_nocam = tc_env_kernel<TC_DEV_KV, false>;
 #else
   auto kern = kv == 5 ? tc_env_kernel<5, true> : kv == 8 ? tc_env_kernel<8, true> : kv == 9 ? tc_env_kernel<9, true> : tc_env_kernel<13, true>;
   auto kern_nocam = kv == 5 ? tc_env_kernel<5, false> : kv == 8 ? tc_env_kernel<8, false> : kv == 9 ? tc_env_kernel<9, false> : tc_env_kernel<13, false>;
@@ -4285,7 +4375,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         fa.r = r;
         fa.pose_rows = e->st_pose;
         fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
-        fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->seg_lds_cap;
+        fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->frame_seg_cap;
         fa.abort_word = e->st_words + 1;
         fa.resident = e->st_words;
         fa.gate_ticks = e->gate_ticks;
@@ -4405,7 +4495,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         fa.pose_rows = e->pose_rows;
         frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
         fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
-        fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->seg_lds_cap;
+        fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->frame_seg_cap;
         // Heaviest frames first.  A dispatch ends with a tail -- the chip half empty while the last workgroups finish, ~36 us
         // of a 16-step dispatch, a fifth of a 5-step one -- and the dispatcher hands workgroups out in index order, so the
         // envs are sorted by the draw-list lengths of the last frame row drawn on this stream (tc_order_kernel with one
@@ -4423,7 +4513,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         if (e->frame_order[fsi]) e->cost_row[fsi] = e->segm_n + ((size_t)r.seg_row0 + (size_t)rows - 1) * N;
       } else {
 #ifdef TC_DEV_FAST
-        auto rk = tc_raster_kernel<true, TC_FMT_CLASSES>;
+        auto rk = tc_raster_kernel<true, TC_DEV_FMTV>;
 #else
         auto rk = thick ? (cls ? tc_raster_kernel<true, TC_FMT_CLASSES> : tc_raster_kernel<true, TC_FMT_RGB>)
                         : (cls ? tc_raster_kernel<false, TC_FMT_CLASSES> : tc_raster_kernel<false, TC_FMT_RGB>);
