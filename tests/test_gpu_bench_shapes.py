@@ -180,7 +180,10 @@ def test_every_switch_gives_the_oracle_rollout(switch, monkeypatch):
         assert info["kernel"] == "tc_env_kernel+tc_raster_kernel", info
 
 
-@pytest.mark.parametrize("switch", [{}, {"TC_GROUPS": "0"}, {"TC_SEG_LDS_CAP": "5"}, {"TC_ENV_GROUPED": "0"}, {"TC_ENVG_MAP_LDS": "0"}],
+@pytest.mark.parametrize("switch", [{}, {"TC_GROUPS": "0"}, {"TC_SEG_LDS_CAP": "5"}, {"TC_ENV_GROUPED": "0"}, {"TC_ENVG_MAP_LDS": "0"},
+                                    {"TC_CAM_GROUP": "0"},      # camera groups of whole layers (no component copy of the map)
+                                    {"TC_CAM_GROUP": "200"},    # more, smaller component groups
+                                    {"TC_CAM_GROUP": "64"}],    # too small for the largest component or too many groups: layer scheme
                          ids=lambda s: ",".join(f"{k}={v}" for k, v in s.items()) or "defaults")
 def test_switches_on_knuffingen(switch, monkeypatch):
     """the switches that only matter on a map with camera layer groups / the K = 13 windowed path"""

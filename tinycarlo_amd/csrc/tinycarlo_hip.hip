@@ -204,11 +204,14 @@ __device__ __forceinline__ const T& kernarg_again(const T& r) {
   return *(const T*)(const __attribute__((address_space(4))) T*)p;
 }
 
-#define RB 32        // segments rasterised per batch
+// Segments rasterised per batch: 32 (64 * 106 bytes of tables per workgroup), or 16 in the kernels of the big-map
+// variants (K >= 8: knuffingen), where the tables' 6.6 KB are what decides how many workgroups a CU holds.
+#define RB_MAX 32
+#define RB_OF_K(K) ((K) >= 8 ? 16 : 32)
 // raster-stage LDS layout (compile-time: folds into instruction offsets and frees SGPRs)
 #define R_OFF_TAB 0
-#define R_TAB_BYTES ((RB * 4 * 5 + RB * 4 + 5 * RB + 8 * RB) * 4 + 2 * 4 * RB * 8)
-#define R_OFF_BITS ((R_TAB_BYTES + 15) / 16 * 16)
+#define R_TAB_BYTES_OF(RB) (((RB) * 4 * 5 + (RB) * 4 + 5 * (RB) + 8 * (RB)) * 4 + 2 * 4 * (RB) * 8)
+#define R_OFF_BITS_OF(RB) ((R_TAB_BYTES_OF(RB) + 15) / 16 * 16)
 #define LCH 8        // outline steps per chunk
 
 #define TC_MAX_GROUPS 8
@@ -270,8 +273,18 @@ struct KArgs {
   int* term_counters;    // [N][TC_MAX_TERMS] (caller owned)
   // camera layer groups: phase C handles lane-line layers grp_layer[g] .. grp_layer[g+1]-1 together (camera.py's
   // per-layer loop makes the layers independent); the LDS node buffer holds cap_nodes nodes, the largest group
+  // Group g = nodes grp_n0[g] .. grp_n0[g+1]-1 and edges grp_e0[g] .. grp_e0[g+1]-1, whose layers are grp_l0[g] ..
+  // grp_l1[g]-1.  Either whole layers of the map's own arrays (cam_nodes == NULL), or -- maps that need groups -- whole
+  // CONNECTED COMPONENTS of the lane-line graph in the env's camera copy of the map (cam_nodes / cam_edges_g: the same
+  // nodes and edges, every layer's edges still contiguous and in their original relative order, components side by
+  // side): camera.py moves a node only along its own edges, so components are as independent as layers are, and a
+  // group no longer has to hold the largest layer (knuffingen: 517 nodes) -- see tc_env_create.
   int n_grp;
   int grp_layer[TC_MAX_GROUPS + 1];
+  int grp_n0[TC_MAX_GROUPS + 1], grp_e0[TC_MAX_GROUPS + 1];
+  int grp_l0[TC_MAX_GROUPS], grp_l1[TC_MAX_GROUPS];
+  const double2* cam_nodes;
+  const int2* cam_edges_g;
   int cap_nodes;
   const int* spawn_tab;  // TC_F_DEVICE_SPAWN: spawnable candidate nodes (library owned), spawn_n > 0 entries
   int spawn_n;
@@ -416,6 +429,23 @@ __device__ inline void cache_nodes(MapCache<K>& c, const DevMap& m, int base, in
   for (int k = 0; k < K; k++) {
     const int i = base + k * TC_NT + tid;
     c.nd[k] = i < end ? m.nodes[i] : make_double2(0.0, 0.0);
+  }
+}
+template <int K>
+__device__ inline void cache_nodes_from(MapCache<K>& c, const double2* nodes, int base, int end, int tid) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int i = base + k * TC_NT + tid;
+    c.nd[k] = i < end ? nodes[i] : make_double2(0.0, 0.0);
+  }
+}
+template <int K>
+__device__ inline void cache_edges_from(MapCache<K>& c, const int2* edges_g, int base, int end, int nbase, int tid) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int e = base + k * TC_NT + tid;
+    int2 ed = e < end ? edges_g[e] : make_int2(nbase, nbase);
+    c.ed[k] = make_int2(ed.x - nbase, ed.y - nbase);
   }
 }
 // node ids are stored relative to `nbase` (the first node of the camera group; 0 for whole-map use)
@@ -890,7 +920,7 @@ __device__ __forceinline__ void sim_body(const KArgs& a, unsigned char* smem, in
   const tc_buffers& b = a.b;
   // map windows of 64*K nodes / edges; one window (the usual case) is fetched now and kept in registers
   const int nwin_n = (m.total_nodes + TC_NT * K - 1) / (TC_NT * K), nwin_e = (m.total_edges + TC_NT * K - 1) / (TC_NT * K);
-  const bool single = a.n_grp == 1 && a.grp_layer[0] == 0 && a.grp_layer[1] == m.C && nwin_n <= 1 && nwin_e <= 1;
+  const bool single = a.n_grp == 1 && !a.cam_nodes && a.grp_layer[0] == 0 && a.grp_layer[1] == m.C && nwin_n <= 1 && nwin_e <= 1;
   double* dn = (double*)(smem + a.lds.off_p);  // phase B: one double per lane-line node (aliases the camera's node buffer)
 
   // ---- state: all lanes read the same LDS words (broadcast)
@@ -1232,7 +1262,7 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
   unsigned int my_layers = 0;  // layers this lane put a segment into the draw list for
   const DevMap& m = a.m;
   const int nwin_n = (m.total_nodes + TC_NT * K - 1) / (TC_NT * K), nwin_e = (m.total_edges + TC_NT * K - 1) / (TC_NT * K);
-  const bool single = a.n_grp == 1 && a.grp_layer[0] == 0 && a.grp_layer[1] == m.C && nwin_n <= 1 && nwin_e <= 1;
+  const bool single = a.n_grp == 1 && !a.cam_nodes && a.grp_layer[0] == 0 && a.grp_layer[1] == m.C && nwin_n <= 1 && nwin_e <= 1;
   if (single && !mc_loaded) {
     cache_nodes(mc, m, 0, m.total_nodes, tid);
     cache_edges(mc, m, 0, m.total_edges, 0, tid);
@@ -1267,15 +1297,20 @@ __device__ __forceinline__ void cam_body(const KArgs& a, unsigned char* smem, in
   int* segg = a.seg_g + seg_slot * a.seg_cap * 5;  // [seg_cap][5]: layer, x0, y0, x1, y1
   int nseg = 0;  // draw-list length so far (wave-uniform)
   for (int g = 0; g < a.n_grp; g++) {
-    const int l0 = a.grp_layer[g], l1 = a.grp_layer[g + 1];
-    const int gn0 = m.node_off[l0], ge0 = m.edge_off[l0];
-    const int nn = m.node_off[l1] - gn0, ne = m.edge_off[l1] - ge0;
+    const int l0 = a.grp_l0[g], l1 = a.grp_l1[g];
+    const int gn0 = a.grp_n0[g], ge0 = a.grp_e0[g];
+    const int nn = a.grp_n0[g + 1] - gn0, ne = a.grp_e0[g + 1] - ge0;
     const int nwn = (nn + TC_NT * K - 1) / (TC_NT * K), nwe = (ne + TC_NT * K - 1) / (TC_NT * K);
     const bool one = nwn <= 1 && nwe <= 1;  // the group fits the register cache: loaded once, serves every pass
     const bool reload = !one;
     if (one && !single) {
-      cache_nodes(mc, m, gn0, gn0 + nn, tid);
-      cache_edges(mc, m, ge0, ge0 + ne, gn0, tid);
+      if (a.cam_nodes) {  // (component groups: always `one`, tc_env_create sees to it)
+        cache_nodes_from(mc, a.cam_nodes, gn0, gn0 + nn, tid);
+        cache_edges_from(mc, a.cam_edges_g, ge0, ge0 + ne, gn0, tid);
+      } else {
+        cache_nodes(mc, m, gn0, gn0 + nn, tid);
+        cache_edges(mc, m, ge0, ge0 + ne, gn0, tid);
+      }
     }
     if (one) {
       cam_group_regs<K>(a, mc, pose, Kc, l0, l1, ge0, nn, ne, Px, Py, Pz, flg, list, segg, (LdsIntPtr)(smem + a.seg_lds_off), nseg,
@@ -1490,13 +1525,13 @@ struct RArgs {
 #define TC_BAND_VMCNT 0
 #endif
 #define TC_BAND_THROTTLE() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TC_BAND_VMCNT) : "memory")
-template <bool THICK, int FMT, bool LDSONLY = false>
+template <bool THICK, int FMT, bool LDSONLY = false, int RB = RB_MAX>
 __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem, int env, unsigned char* obs_base,
                                             const int tid, const size_t seg_slot0, const int nseg_in,
                                             const unsigned int used_in, const int frame_row) {
   const RArgs& a = a0;
   const RCam& cam = a.cam;
-  unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS);
+  unsigned int* bits = (unsigned int*)(smem + R_OFF_BITS_OF(RB));
   const int* segg = a.seg_g + (seg_slot0 + env) * a.seg_cap * 5;
   // draw-list entry k: from LDS when the camera stage of this wavefront left it there (tc_frame_kernel), else global
   const LdsIntPtr seg_lds = (LdsIntPtr)(smem + a.seg_lds_off);
@@ -1619,7 +1654,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
         continue;
       }
     }
-    {  // (R_OFF_BITS is a multiple of 16: whole 16-byte writes, then the odd words)
+    {  // (R_OFF_BITS_OF(RB) is a multiple of 16: whole 16-byte writes, then the odd words)
       const int n4 = nwords >> 2;
       for (int i = tid; i < n4; i += TC_NT) ((uint4*)bits)[i] = make_uint4(0, 0, 0, 0);
       for (int i = (n4 << 2) + tid; i < nwords; i += TC_NT) bits[i] = 0;
@@ -1763,15 +1798,21 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
         lds_sync();
         MARK("prefix sums");
         int tot_l, tot_f;
-        {  // exclusive prefix sums (RB*4 = 2 entries per lane; RB entries on the low lanes)
-          int v0 = lc[2 * tid], v1 = lc[2 * tid + 1];
+        {  // exclusive prefix sums (RB*4 = 2 entries per lane, or 1 when RB = 16; RB entries on the low lanes)
+          static_assert(RB * 4 == 2 * TC_NT || RB * 4 == TC_NT, "outline-edge chunk counts: one or two per lane");
+          constexpr bool TWO = RB * 4 == 2 * TC_NT;
+          int v0 = TWO ? lc[2 * tid] : lc[tid], v1 = TWO ? lc[2 * tid + 1] : 0;
           int inc = wave_incl_scan(v0 + v1, tid);
           tot_l = __builtin_amdgcn_readlane(inc, TC_NT - 1);
           int f = tid < RB ? fc[tid] : 0;
           int finc = wave_incl_scan(f, tid);
           tot_f = __builtin_amdgcn_readlane(finc, TC_NT - 1);
-          lc[2 * tid] = inc - v0 - v1;  // each lane rewrites only the entries it read
-          lc[2 * tid + 1] = inc - v1;
+          if (TWO) {
+            lc[2 * tid] = inc - v0 - v1;  // each lane rewrites only the entries it read
+            lc[2 * tid + 1] = inc - v1;
+          } else {
+            lc[tid] = inc - v0;
+          }
           if (tid < RB) fc[tid] = finc - f;
         }
         lds_sync();
@@ -1829,7 +1870,7 @@ __device__ __forceinline__ void raster_body(const RArgs& a0, unsigned char* smem
       const int nbl = a.noise_blobs, nb = C * nbl, mr = a.noise_max_radius;
       int* bp = (int*)(smem + R_OFF_TAB);                 // [nb][2] (x | y << 16), (r | mode << 12 | src << 16): the
       unsigned char* bh = (unsigned char*)(bp + 2 * nb);  // raster tables are dead here;  [nb][rows] half widths
-      const bool staged = nb * 8 + nb * rows <= R_TAB_BYTES;
+      const bool staged = nb * 8 + nb * rows <= R_TAB_BYTES_OF(RB);
       const unsigned int nstep = *a.noise_step + (unsigned int)frame_row;
       for (int k = tid; k < nb; k += TC_NT) {
         const tc_blob bl = tc_noise_blob(a.noise_seed, (uint32_t)env, nstep, (uint32_t)k, W, H, mr, C);
@@ -2812,7 +2853,7 @@ __device__ __forceinline__ bool frame_pose(const size_t slot0, const int env, co
 
 // One frame: `rowy` is the frame's row in the launch (its step), `env` its env.
 // HOT (tc_frame_kernel): the raster stage in its LDS-only form (see raster_body); !HOT (the recover kernel): the generic form.
-template <int K, bool THICK, int FMT, bool HOT>
+template <int K, bool THICK, int FMT, bool HOT, int RBT>
 __device__ __forceinline__ void frame_one(unsigned char* smem, const int env, const int rowy) {
   const int tid = threadIdx.x;
   int nseg;
@@ -2844,8 +2885,8 @@ __device__ __forceinline__ void frame_one(unsigned char* smem, const int env, co
   } else {
     lds_sync();
   }
-  raster_body<THICK, FMT, HOT>(fr.r, smem, env, fr.r.obs + (size_t)rowy * fr.r.obs_row_stride, tid, slot0, nseg, used,
-                               fr.r.noise_row0 + rowy);
+  raster_body<THICK, FMT, HOT, RBT>(fr.r, smem, env, fr.r.obs + (size_t)rowy * fr.r.obs_row_stride, tid, slot0, nseg, used,
+                                           fr.r.noise_row0 + rowy);
   {
     const FrameArgs& fe = frame_args();
     const size_t slot = (size_t)(fe.r.seg_row0 + rowy) * fe.a.N + env;
@@ -2858,14 +2899,17 @@ __device__ __forceinline__ void frame_one(unsigned char* smem, const int env, co
   TSTAMP_DUMP(env);
 }
 
-template <int K, bool THICK, int FMT>
+// K: slots of the camera stage's register cache per lane (a camera group has at most 64 K nodes / edges); RBT: segments per
+// raster batch.  K = 5 with RBT = 16 is the variant of maps whose camera groups are packs of connected components (knuffingen:
+// the map needs K = 9 as a whole or layer by layer, its component groups fit K = 5).
+template <int K, bool THICK, int FMT, int RBT = RB_OF_K(K)>
 __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame_kernel(FrameArgs fa_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   const FrameArgs& fa = frame_args();
   if ((int)blockIdx.x >= fa.a.N) return;
   const int env = fa.order ? uni_i(((const __attribute__((address_space(4))) int*)(unsigned long long)fa.order)[blockIdx.x])
                            : fa.a.env0 + (int)blockIdx.x;
-  frame_one<K, THICK, FMT, true>(smem, env, (int)blockIdx.y);
+  frame_one<K, THICK, FMT, true, RBT>(smem, env, (int)blockIdx.y);
 }
 
 // The pass behind a streamed call's simulate launch: one workgroup per env looks through the call's rows for frames a
@@ -2873,7 +2917,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_frame
 // itself, one after the other, with gate = 2 (the row is there: read once, no waiting) and the generic form of both
 // stages.  Workgroup 0 resets the call's two words.
 // Never on the hot path, so what the step loop around a ~10 k-instruction body costs in registers does not matter.
-template <int K, bool THICK, int FMT>
+template <int K, bool THICK, int FMT, int RBT = RB_OF_K(K)>
 __global__ __launch_bounds__(TC_NT) void tc_frame_recover_kernel(FrameArgs fa_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   const FrameArgs& fa = frame_args();
@@ -2890,7 +2934,7 @@ __global__ __launch_bounds__(TC_NT) void tc_frame_recover_kernel(FrameArgs fa_un
   for (int r = 0; r < rows; r++) {
     const FrameArgs& fb = frame_args();
     if (uni_i(((const volatile int*)fb.a.seg_n)[(size_t)(fb.r.seg_row0 + r) * fb.a.N + env]) >= 0) continue;
-    frame_one<K, THICK, FMT, false>(smem, env, r);
+    frame_one<K, THICK, FMT, false, RBT>(smem, env, r);
     __syncthreads();  // the next frame reuses the LDS
   }
 }
@@ -2938,7 +2982,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
       const StepArgs& sb = step_args();
       const size_t obs_step = sb.ma.roll.obs ? (size_t)sb.a.N * ((size_t)sb.r.cam.H * sb.r.cam.W * (FMT == TC_FMT_CLASSES ? sb.r.C : 3)) : 0;
       unsigned char* obs_base = sb.ma.roll.obs ? sb.ma.roll.obs : sb.r.obs;
-      raster_body<THICK, FMT>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid, 0, nseg, used, k);
+      raster_body<THICK, FMT, false, RB_OF_K(K)>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid, 0, nseg, used, k);
       if (tid == 0) step_args().a.seg_n[env] = nseg;  // workload statistics only
     } else {
       lds_sync();  // the next step reads the LiveLds record this one wrote
@@ -3033,24 +3077,37 @@ static fused_kern_t pick_fused(bool thick, bool cls) {
 }
 
 typedef void (*frame_kern_t)(FrameArgs);
-template <int K>
+#ifndef TC_DEV_FK   // dev builds: K / batch size of the one frame kernel variant compiled (cfg4, cfg5: DEVFK=5 DEVFRB=16)
+#define TC_DEV_FK TC_DEV_KV
+#endif
+#ifndef TC_DEV_FRB
+#define TC_DEV_FRB RB_OF_K(TC_DEV_FK)
+#endif
+template <int K, int RBT = RB_OF_K(K)>
 static frame_kern_t pick_frame(bool thick, bool cls) {
 #ifdef TC_DEV_FAST
-  return tc_frame_kernel<TC_DEV_KV, true, TC_DEV_FMTV>;
+  return tc_frame_kernel<TC_DEV_FK, true, TC_DEV_FMTV, TC_DEV_FRB>;
 #else
-  return thick ? (cls ? tc_frame_kernel<K, true, TC_FMT_CLASSES> : tc_frame_kernel<K, true, TC_FMT_RGB>)
-               : (cls ? tc_frame_kernel<K, false, TC_FMT_CLASSES> : tc_frame_kernel<K, false, TC_FMT_RGB>);
+  return thick ? (cls ? tc_frame_kernel<K, true, TC_FMT_CLASSES, RBT> : tc_frame_kernel<K, true, TC_FMT_RGB, RBT>)
+               : (cls ? tc_frame_kernel<K, false, TC_FMT_CLASSES, RBT> : tc_frame_kernel<K, false, TC_FMT_RGB, RBT>);
 #endif
 }
 
-template <int K>
+template <int K, int RBT = RB_OF_K(K)>
 static frame_kern_t pick_recover(bool thick, bool cls) {
 #ifdef TC_DEV_FAST
-  return tc_frame_recover_kernel<TC_DEV_KV, true, TC_DEV_FMTV>;
+  return tc_frame_recover_kernel<TC_DEV_FK, true, TC_DEV_FMTV, TC_DEV_FRB>;
 #else
-  return thick ? (cls ? tc_frame_recover_kernel<K, true, TC_FMT_CLASSES> : tc_frame_recover_kernel<K, true, TC_FMT_RGB>)
-               : (cls ? tc_frame_recover_kernel<K, false, TC_FMT_CLASSES> : tc_frame_recover_kernel<K, false, TC_FMT_RGB>);
+  return thick ? (cls ? tc_frame_recover_kernel<K, true, TC_FMT_CLASSES, RBT> : tc_frame_recover_kernel<K, true, TC_FMT_RGB, RBT>)
+               : (cls ? tc_frame_recover_kernel<K, false, TC_FMT_CLASSES, RBT> : tc_frame_recover_kernel<K, false, TC_FMT_RGB, RBT>);
 #endif
+}
+// by tc_env::kframe: the simulate variant's K, or 516 = K 5 with batches of 16
+static frame_kern_t frame_kernel_of(int kframe, bool thick, bool cls) {
+  return kframe == 516 ? pick_frame<5, 16>(thick, cls) : kframe == 5 ? pick_frame<5>(thick, cls) : kframe == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
+}
+static frame_kern_t recover_kernel_of(int kframe, bool thick, bool cls) {
+  return kframe == 516 ? pick_recover<5, 16>(thick, cls) : kframe == 5 ? pick_recover<5>(thick, cls) : kframe == 8 ? pick_recover<8>(thick, cls) : pick_recover<9>(thick, cls);
 }
 
 // =============================================================================================
@@ -3074,6 +3131,8 @@ struct tc_map {
   DevMap d;
   std::vector<void*> allocs;
   int device;
+  std::vector<double2> h_nodes;   // host copies of d.nodes / d.edges_g (tc_env_create groups the camera's copy by them)
+  std::vector<int2> h_edges_g;
 };
 
 struct tc_env {
@@ -3127,6 +3186,8 @@ struct tc_env {
   int order_every, order_calls;
   int seg_lds_limit;  // TC_SEG_LDS_CAP
   int frame_lds, seg_lds_off, seg_lds_cap;  // tc_frame_kernel: LDS bytes per workgroup, draw-list region (see KArgs)
+  void *cam_nodes_dev, *cam_edges_dev;  // the camera's copy of the map, grouped by connected components (or NULL)
+  int kframe;  // tc_frame_kernel variant: kvar, or 516 (K = 5, batches of 16) when every component group fits 320 nodes / edges
   int frame_seg_cap;  // tc_frame_kernel's own capacity: seg_lds_cap, but never below 8 (its raster stage reads the list from LDS only)
   int frame_streams;  // short K-step calls: frame launches of consecutive chunks alternate between two streams (TC_FRAME_STREAMS)
   int prof_piped[TC_PROF_RING];
@@ -3359,6 +3420,8 @@ extern "C" int tc_map_create(const tc_map_desc* desc, tc_map** out) {
   UP(lpo, lp_ori) UP(noff, next_off) UP(nnode, next_node) UP(nori, next_ori) UP(poff, prev_off)
   UP(pnode, prev_node) UP(pori, prev_ori) UP(coff, cand_off) UP(cidx, cand_idx)
 #undef UP
+  m->h_nodes = nodes;
+  m->h_edges_g = edges_g;
   if (rc != TC_OK) {
     tc_map_destroy(m);
     return rc;
@@ -3535,6 +3598,154 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
       }
     }
   }
+  // group bounds of the layer scheme (or of the single group)
+  e->k.cam_nodes = nullptr;
+  e->k.cam_edges_g = nullptr;
+  e->cam_nodes_dev = e->cam_edges_dev = nullptr;
+  for (int g = 0; g <= e->k.n_grp; g++) {
+    e->k.grp_n0[g] = m.node_off[e->k.grp_layer[g]];
+    e->k.grp_e0[g] = m.edge_off[e->k.grp_layer[g]];
+  }
+  for (int g = 0; g < e->k.n_grp; g++) {
+    e->k.grp_l0[g] = e->k.grp_layer[g];
+    e->k.grp_l1[g] = e->k.grp_layer[g + 1];
+  }
+  // Component groups.  The layer scheme leaves the LDS node buffer at the size of the largest LAYER (knuffingen: 517 of
+  // 827 nodes, 12.4 KB of a workgroup's 17.4 KB), and that buffer is what decides how many frame workgroups a CU holds
+  // (9).  A layer is not the unit of independence, though: camera.py's fix-up passes move a node along its own edges
+  // only, so every connected component of the lane-line graph (a dash of a dashed line is one) can be processed on its
+  // own.  The camera stage therefore works from a copy of the map in which the components of each layer stand side by
+  // side -- nodes renumbered, every layer's edges still contiguous and in their original relative order (the replay of a
+  // fix-up chain follows edge order, and a chain never leaves its component) -- packed greedily into groups of at most
+  // TC_CAM_GROUP nodes / edges (default 320: the buffer shrinks to 7.7 KB).  Nodes without an edge are never drawn and
+  // are left out.  Falls back to the layer scheme when a component is larger than that or the groups are too many.
+  if (e->k.n_grp >= 2 && e->kvar == 9 && (int)map->h_nodes.size() == m.total_nodes && (int)map->h_edges_g.size() == m.total_edges) {
+    int T = 5 * TC_NT;
+    if (const char* cg = getenv("TC_CAM_GROUP")) T = atoi(cg);
+    if (T >= TC_NT && T <= 9 * TC_NT) {
+      const int TN = m.total_nodes, TE = m.total_edges;
+      std::vector<int> parent(TN);
+      for (int i = 0; i < TN; i++) parent[i] = i;
+      auto find = [&](int x) {
+        while (parent[x] != x) x = parent[x] = parent[parent[x]];
+        return x;
+      };
+      for (int ed = 0; ed < TE; ed++) {
+        const int a0 = find(map->h_edges_g[ed].x), b0 = find(map->h_edges_g[ed].y);
+        if (a0 != b0) parent[b0 > a0 ? b0 : a0] = b0 > a0 ? a0 : b0;
+      }
+      // components in order of their first edge (edges are layer by layer, so components are too)
+      std::vector<int> comp_of_root(TN, -1), comp_first_edge, comp_nn, comp_ne;
+      std::vector<int> edge_comp(TE);
+      for (int ed = 0; ed < TE; ed++) {
+        const int r = find(map->h_edges_g[ed].x);
+        if (comp_of_root[r] < 0) {
+          comp_of_root[r] = (int)comp_first_edge.size();
+          comp_first_edge.push_back(ed);
+          comp_nn.push_back(0);
+          comp_ne.push_back(0);
+        }
+        edge_comp[ed] = comp_of_root[r];
+        comp_ne[edge_comp[ed]]++;
+      }
+      std::vector<int> node_comp(TN, -1);
+      for (int i = 0; i < TN; i++) {
+        const int c = comp_of_root[find(i)];
+        node_comp[i] = c;  // -1: a node without an edge
+        if (c >= 0) comp_nn[c]++;
+      }
+      const int NC = (int)comp_first_edge.size();
+      bool ok = NC > 0;
+      for (int c = 0; c < NC && ok; c++) ok = comp_nn[c] <= T && comp_ne[c] <= T;
+      // a component's edges must all belong to one layer (they do: edges join nodes of their own layer) and components
+      // must appear layer by layer, so that an edge's position in the new order is its position in the old one's layer
+      std::vector<int> grp_first_comp;
+      if (ok) {
+        int gn = 0, ge = 0;
+        grp_first_comp.push_back(0);
+        for (int c = 0; c < NC; c++) {
+          if (gn + comp_nn[c] > T || ge + comp_ne[c] > T) {
+            grp_first_comp.push_back(c);
+            gn = ge = 0;
+          }
+          gn += comp_nn[c];
+          ge += comp_ne[c];
+        }
+        grp_first_comp.push_back(NC);
+        ok = (int)grp_first_comp.size() - 1 <= TC_MAX_GROUPS;
+      }
+      if (ok) {
+        // new node ids: components in order, nodes of a component in their old order; new edge order: by component,
+        // old order inside -- which is the old order within each layer as long as a layer's components are visited in
+        // the order of their first edges AND no component's edges interleave with another's inside a layer.  They may
+        // (two dashes drawn alternately), so the edges are NOT moved: an edge keeps its index and only its node ids
+        // change; a group's edges are then the index range from its first component's first edge to its last
+        // component's last edge, which must not contain edges of other groups' components -- checked below.
+        std::vector<int> new_id(TN, -1);
+        std::vector<int> comp_n0(NC + 1, 0);
+        for (int c = 0; c < NC; c++) comp_n0[c + 1] = comp_n0[c] + comp_nn[c];
+        std::vector<int> fill(comp_n0.begin(), comp_n0.end() - 1);
+        for (int i = 0; i < TN; i++)
+          if (node_comp[i] >= 0) new_id[i] = fill[node_comp[i]]++;
+        std::vector<int> comp_last_edge(NC, -1);
+        for (int ed = 0; ed < TE; ed++) comp_last_edge[edge_comp[ed]] = ed;
+        const int NG = (int)grp_first_comp.size() - 1;
+        std::vector<int> ge0(NG + 1), gn0(NG + 1);
+        for (int g = 0; g < NG && ok; g++) {
+          const int c0 = grp_first_comp[g], c1 = grp_first_comp[g + 1];
+          int lo = TE, hi = -1;
+          for (int c = c0; c < c1; c++) {
+            lo = comp_first_edge[c] < lo ? comp_first_edge[c] : lo;
+            hi = comp_last_edge[c] > hi ? comp_last_edge[c] : hi;
+          }
+          ge0[g] = lo;
+          gn0[g] = comp_n0[c0];
+          for (int ed = lo; ed <= hi && ok; ed++) ok = edge_comp[ed] >= c0 && edge_comp[ed] < c1;
+          if (g > 0) ok = ok && lo == ge0[g - 1] + [&] { int n = 0; for (int c = grp_first_comp[g - 1]; c < c0; c++) n += comp_ne[c]; return n; }();
+        }
+        ge0[NG] = TE;
+        gn0[NG] = comp_n0[NC];
+        ok = ok && ge0[0] == 0;
+        if (ok) {
+          std::vector<double2> cn((size_t)comp_n0[NC]);
+          std::vector<int2> ce((size_t)TE);
+          for (int i = 0; i < TN; i++)
+            if (new_id[i] >= 0) cn[new_id[i]] = map->h_nodes[i];
+          for (int ed = 0; ed < TE; ed++) ce[ed] = make_int2(new_id[map->h_edges_g[ed].x], new_id[map->h_edges_g[ed].y]);
+          void *dn = nullptr, *de = nullptr;
+          if (hipMalloc(&dn, cn.size() * sizeof(double2)) == hipSuccess && hipMalloc(&de, ce.size() * sizeof(int2)) == hipSuccess &&
+              hipMemcpy(dn, cn.data(), cn.size() * sizeof(double2), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(de, ce.data(), ce.size() * sizeof(int2), hipMemcpyHostToDevice) == hipSuccess) {
+            e->cam_nodes_dev = dn;
+            e->cam_edges_dev = de;
+            e->k.cam_nodes = (const double2*)dn;
+            e->k.cam_edges_g = (const int2*)de;
+            e->k.n_grp = NG;
+            cap_n = cap_e = 0;
+            for (int g = 0; g <= NG; g++) {
+              e->k.grp_n0[g] = gn0[g];
+              e->k.grp_e0[g] = ge0[g];
+            }
+            for (int g = 0; g < NG; g++) {
+              const int nl = gn0[g + 1] - gn0[g], el = ge0[g + 1] - ge0[g];
+              cap_n = nl > cap_n ? nl : cap_n;
+              cap_e = el > cap_e ? el : cap_e;
+              int la = 0, lb = 0;
+              while (la + 1 < m.C && ge0[g] >= m.edge_off[la + 1]) la++;
+              while (lb + 1 < m.C && ge0[g + 1] - 1 >= m.edge_off[lb + 1]) lb++;
+              e->k.grp_l0[g] = la;
+              e->k.grp_l1[g] = lb + 1;
+            }
+          } else {
+            if (dn) (void)hipFree(dn);
+            if (de) (void)hipFree(de);
+          }
+        }
+      }
+    }
+  }
+  e->kframe = e->kvar;
+  if (e->k.cam_nodes && cap_n <= 5 * TC_NT && cap_e <= 5 * TC_NT) e->kframe = 516;
   e->k.cap_nodes = cap_n > 0 ? cap_n : 1;
   LdsLayout& L = e->k.lds;
   int off = 0;
@@ -3555,18 +3766,21 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
   // CU holds decides the rate of the big frames (cfg5: 6 per CU at 23.2 KB, 9 at 17.4 KB: 3.10 -> 3.82 M env-steps/s).
   // So the band shrinks until the raster stage needs no more than the camera stage does anyway -- not further: more
   // bands only repeat the per-band set-up (measured: 8 KB and 6 KB bands are slower again).
+  // (tables of the batch size the fused / frame kernels of this variant are compiled with; tc_raster_kernel: RB_MAX)
+  const int r_off_bits_k = e->kvar == 13 ? R_OFF_BITS_OF(RB_MAX) : (e->kvar >= 8 ? R_OFF_BITS_OF(RB_OF_K(8)) : R_OFF_BITS_OF(RB_OF_K(5)));
   if (dc.n_bands > 1 && !getenv("TC_BAND_BYTES")) {
-    const int fit = (L.total - R_OFF_BITS) / row_bytes;
+    const int fit = (L.total - r_off_bits_k) / row_bytes;
     if (fit >= 8 && fit < dc.band_rows) {
       dc.band_rows = band_rows = fit;
       dc.n_bands = (dc.H + band_rows - 1) / band_rows;
     }
   }
   e->r_off_tab = R_OFF_TAB;
-  e->r_off_bits = R_OFF_BITS;
+  e->r_off_bits = R_OFF_BITS_OF(RB_MAX);
   e->r_lds = e->r_off_bits + align_up(m.C * band_rows * dc.wpr * 4, 16);
   // the env's parked state (tc_step_multi) sits behind whichever stage needs more, so that neither aliases it
-  L.off_live = align_up(L.total > e->r_lds ? L.total : e->r_lds, 16);
+  const int r_lds_k = r_off_bits_k + align_up(m.C * band_rows * dc.wpr * 4, 16);
+  L.off_live = align_up(L.total > r_lds_k ? L.total : r_lds_k, 16);
   L.total = L.off_live + TC_LIVE_BYTES;
   {
     // tc_frame_kernel keeps no env state in LDS, so the bytes behind both stages' buffers -- the LiveLds slot and whatever
@@ -3631,6 +3845,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
           (void)hipFuncSetAttribute((const void*)pick_fused<8>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_fused<9>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_frame<5>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          (void)hipFuncSetAttribute((const void*)pick_frame<5, 16>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_frame<8>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_frame<9>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
@@ -3767,6 +3982,8 @@ extern "C" int tc_env_destroy(tc_env* e) {
     if (e->st_segm_n) (void)hipFree(e->st_segm_n);
     if (e->st_pose) (void)hipFree(e->st_pose);
     if (e->st_words) (void)hipFree(e->st_words);
+    if (e->cam_nodes_dev) (void)hipFree(e->cam_nodes_dev);
+    if (e->cam_edges_dev) (void)hipFree(e->cam_edges_dev);
     if (e->frames_ev) (void)hipEventDestroy(e->frames_ev);
   }
   if (e && e->segm_g) (void)hipFree(e->segm_g);
@@ -4384,7 +4601,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         hipLaunchKernelGGL(tc_gate_kernel, dim3(1), dim3(64), 0, fs, (const unsigned int*)e->st_words, sim_wgs, e->gate_ticks);
         HIP_TRY(hipGetLastError());
         if (prof && si == 0) HIP_TRY(hipEventRecord(e->ev[3][slot], fs));
-        frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
+        frame_kern_t fk = frame_kernel_of(e->kframe, thick, cls);
         fa.gate = 1;
         hipLaunchKernelGGL(fk, dim3(N, cn), dim3(TC_NT), e->frame_lds, fs, fa);
         HIP_TRY(hipGetLastError());
@@ -4392,7 +4609,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         fa.gate = 2;
         fa.recover_rows = cn;
         fa.order = nullptr;
-        frame_kern_t rk = kv == 5 ? pick_recover<5>(thick, cls) : kv == 8 ? pick_recover<8>(thick, cls) : pick_recover<9>(thick, cls);
+        frame_kern_t rk = recover_kernel_of(e->kframe, thick, cls);
         hipLaunchKernelGGL(rk, dim3(N), dim3(TC_NT), e->frame_lds, fs, fa);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->slot_ev[0], fs));
@@ -4493,7 +4710,7 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         fa.a.seg_n = e->segm_n;
         fa.r = r;
         fa.pose_rows = e->pose_rows;
-        frame_kern_t fk = kv == 5 ? pick_frame<5>(thick, cls) : kv == 8 ? pick_frame<8>(thick, cls) : pick_frame<9>(thick, cls);
+        frame_kern_t fk = frame_kernel_of(e->kframe, thick, cls);
         fa.a.seg_lds_off = fa.r.seg_lds_off = e->seg_lds_off;
         fa.a.seg_lds_cap = fa.r.seg_lds_cap = e->frame_seg_cap;
         // Heaviest frames first.  A dispatch ends with a tail -- the chip half empty while the last workgroups finish, ~36 us

@@ -5,8 +5,6 @@ cd $R
 ARGS="$1"; shift
 for rep in 1 2; do
   for lib in "$@"; do
-    TINYCARLO_HIP_LIB=$R/tinycarlo_amd/$lib timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline --no-single-step 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']
-print('%-12s' % '$lib', round(d['value']/1e6,2), 'M/s', round(d['ms_per_step']*1e3,2), 'us/step', {k:round(v,1) for k,v in r['kernels_us'].items()}, 'spd', r['steps_per_dispatch'])"
+    TINYCARLO_HIP_LIB=$R/tinycarlo_amd/$lib timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline --no-single-step 2>/dev/null | python tools/ab_line.py $lib
   done
 done
