@@ -2942,7 +2942,7 @@ __global__ __launch_bounds__(TC_NT) void tc_frame_recover_kernel(FrameArgs fa_un
 // All stages in one launch: the same wavefront simulates its env, runs the camera and rasterises the frame.  The form
 // of tc_step / tc_reset / tc_render (one step: nothing to balance, and one kernel boundary less), and of tc_step_multi
 // under TC_MULTI_SPLIT=0.
-template <int K, bool THICK, int FMT>
+template <int K, bool THICK, int FMT, int RBT = RB_OF_K(K)>
 __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_kernel(StepArgs sa_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   const StepArgs& s0 = step_args();
@@ -2982,7 +2982,7 @@ __global__ __launch_bounds__(TC_NT, (K <= 5 ? 4 : K <= 9 ? 3 : 2)) void tc_step_
       const StepArgs& sb = step_args();
       const size_t obs_step = sb.ma.roll.obs ? (size_t)sb.a.N * ((size_t)sb.r.cam.H * sb.r.cam.W * (FMT == TC_FMT_CLASSES ? sb.r.C : 3)) : 0;
       unsigned char* obs_base = sb.ma.roll.obs ? sb.ma.roll.obs : sb.r.obs;
-      raster_body<THICK, FMT, false, RB_OF_K(K)>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid, 0, nseg, used, k);
+      raster_body<THICK, FMT, false, RBT>(sb.r, smem, env, obs_base + (size_t)k * obs_step, tid, 0, nseg, used, k);
       if (tid == 0) step_args().a.seg_n[env] = nseg;  // workload statistics only
     } else {
       lds_sync();  // the next step reads the LiveLds record this one wrote
@@ -3066,13 +3066,19 @@ typedef void (*fused_kern_t)(StepArgs);
 #ifndef TC_DEV_FMTV
 #define TC_DEV_FMTV TC_FMT_CLASSES
 #endif
-template <int K>
+#ifndef TC_DEV_SK   // K / batch size of the one fused step kernel variant compiled (cfg4, cfg5: 5 and 16, like TC_DEV_FK / TC_DEV_FRB)
+#define TC_DEV_SK TC_DEV_KV
+#endif
+#ifndef TC_DEV_SRB
+#define TC_DEV_SRB RB_OF_K(TC_DEV_SK)
+#endif
+template <int K, int RBT = RB_OF_K(K)>
 static fused_kern_t pick_fused(bool thick, bool cls) {
 #ifdef TC_DEV_FAST
-  return tc_step_kernel<TC_DEV_KV, true, TC_DEV_FMTV>;
+  return tc_step_kernel<TC_DEV_SK, true, TC_DEV_FMTV, TC_DEV_SRB>;
 #else
-  return thick ? (cls ? tc_step_kernel<K, true, TC_FMT_CLASSES> : tc_step_kernel<K, true, TC_FMT_RGB>)
-               : (cls ? tc_step_kernel<K, false, TC_FMT_CLASSES> : tc_step_kernel<K, false, TC_FMT_RGB>);
+  return thick ? (cls ? tc_step_kernel<K, true, TC_FMT_CLASSES, RBT> : tc_step_kernel<K, true, TC_FMT_RGB, RBT>)
+               : (cls ? tc_step_kernel<K, false, TC_FMT_CLASSES, RBT> : tc_step_kernel<K, false, TC_FMT_RGB, RBT>);
 #endif
 }
 
@@ -3842,6 +3848,7 @@ extern "C" int tc_env_create(const tc_map* map, const tc_car_params* car, const 
       for (int t = 0; t < 2; t++)
         for (int c = 0; c < 2; c++) {
           (void)hipFuncSetAttribute((const void*)pick_fused<5>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          (void)hipFuncSetAttribute((const void*)pick_fused<5, 16>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_fused<8>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_fused<9>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           (void)hipFuncSetAttribute((const void*)pick_frame<5>(t, c), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -4598,7 +4605,9 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
         fa.gate_ticks = e->gate_ticks;
         fa.gate_test = e->gate_test;
         if (e->frame_order[0] && e->frame_order_valid[0]) fa.order = e->frame_order[0];
-        hipLaunchKernelGGL(tc_gate_kernel, dim3(1), dim3(64), 0, fs, (const unsigned int*)e->st_words, sim_wgs, e->gate_ticks);
+        // (ten times the patience of a frame workgroup: one idle wavefront costs nothing, and when another env's frame
+        // launch has the chip -- two handles stepping on one GPU -- the simulate workgroups only get on as that launch drains)
+        hipLaunchKernelGGL(tc_gate_kernel, dim3(1), dim3(64), 0, fs, (const unsigned int*)e->st_words, sim_wgs, 10 * e->gate_ticks);
         HIP_TRY(hipGetLastError());
         if (prof && si == 0) HIP_TRY(hipEventRecord(e->ev[3][slot], fs));
         frame_kern_t fk = frame_kernel_of(e->kframe, thick, cls);
@@ -4772,7 +4781,12 @@ static int launch(tc_env* e, int mode, const void* cc, int cdtype, const int32_t
   if (do_raster && e->fuse && kv != 13) {  // one launch: simulate + raster by the same wavefront
     // (the register-hungry K = 13 simulate stage spills when fused, so it stays two launches)
     const bool thick = e->k.cam.thickness > 1, cls = e->k.cam.format == TC_FMT_CLASSES;
-    fused_kern_t fk = kv == 5 ? pick_fused<5>(thick, cls) : kv == 8 ? pick_fused<8>(thick, cls) : pick_fused<9>(thick, cls);
+    // (component groups that fit the K = 5 register cache: the K = 5 kernel with 16-segment batches, as for the frame kernel --
+    // its simulate stage then walks the map's lane-line nodes in windows of 320 instead of 576)
+    fused_kern_t fk = e->kframe == 516 ? pick_fused<5, 16>(thick, cls)
+                      : kv == 5        ? pick_fused<5>(thick, cls)
+                      : kv == 8        ? pick_fused<8>(thick, cls)
+                                       : pick_fused<9>(thick, cls);
     KArgs k = e->k;
     k.env0 = 0;
     RArgs r = make_rargs(e, e->k.seg_g, e->k.seg_n, e->k.seg_cap, nullptr, flags, 0, nullptr, mode == MODE_STEP);
@@ -4918,7 +4932,7 @@ extern "C" int tc_env_launch_info(const tc_env* e, uint32_t flags, int32_t n_ste
   const bool do_raster = !(flags & (TC_F_NO_OBSERVATION | DBG_SKIP_CAMERA)) && e->k.b.obs;
   const bool f = fused_path(e, flags) && !(n_steps > 1 && e->multi_split);
   if (fused) *fused = f ? 1 : 0;
-  if (kvar) *kvar = e->kvar;
+  if (kvar) *kvar = (f && e->kframe == 516) ? 5 : e->kvar;  // (the fused kernel of a map with component groups: K = 5)
   const bool frames = n_steps > 1 && do_raster && !f && e->fuse && e->kvar != 13;
   const bool streamed = frames && e->env_grouped && e->pipe && e->stream && e->st_rows >= 2;  // (as in launch())
   if (steps_per_dispatch)
