@@ -2558,6 +2558,36 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
       have_trig = true;
     }
     TSTAMP(27);
+    // ---- this step's pose row, as early as the pose is final (nothing below moves the car): in a streamed call the frame
+    // workgroups of this (step, env) are waiting for it, and what follows -- distances, reward, rollout rows -- is more
+    // than half of the step
+    if (sa.ma.pose_rows) {
+      // car.py:159-165 takes cos(-theta), sin(-theta): tc_cos is exactly even and tc_sin exactly odd, so the values of
+      // the front-axle update are reused bit for bit (as in sim_body)
+      FramePose fp;
+      fp.x = s.x;
+      fp.y = s.y;
+      fp.cth = have_trig ? s.cth : tc_cos(-s.theta);
+      fp.sth = have_trig ? -s.sth : tc_sin(-s.theta);
+      double pose[12];
+      cam_pose12(sa.a, live ? env : 0, fp, pose);
+      if (live && sub == 0) {
+        if (sa.ma.resident) {
+          // streamed call: the frame workgroup of this (step, env) may already be polling the row.  Each entry is one
+          // 8-byte device-scope store (sc1: written through to where every XCD sees it) and validates itself -- the
+          // reader waits until none of the twelve holds TC_POSE_EMPTY any more -- so the stores need no order among
+          // themselves and this wavefront waits for none of them.
+          unsigned long long* o = (unsigned long long*)(sa.ma.pose_rows + (row0 + env) * TC_POSE_ROW);
+#pragma unroll
+          for (int i = 0; i < 12; i++)
+            __hip_atomic_store(o + i, (unsigned long long)__double_as_longlong(pose[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          double2* o = (double2*)(sa.ma.pose_rows + (row0 + env) * TC_POSE_ROW);
+#pragma unroll
+          for (int i = 0; i < 6; i++) o[i] = make_double2(pose[2 * i], pose[2 * i + 1]);
+        }
+      }
+    }
     // ---- info (car.py:46-53), default reward / termination (env.py:93,99)
     const bool have_info = !fresh && s.lp_len >= 2;
     cte = 0;
@@ -2715,33 +2745,6 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
         int4* o = (int4*)(roll.lp + (roll.row0 + env) * 8);
         o[0] = make_int4(s.lp[0], s.lp[1], s.lp[2], s.lp[3]);
         o[1] = make_int4(s.lp[4], s.lp[5], s.lp[6], s.lp[7]);
-      }
-    }
-    if (sa.ma.pose_rows) {
-      // car.py:159-165 takes cos(-theta), sin(-theta): tc_cos is exactly even and tc_sin exactly odd, so the values of
-      // the front-axle update are reused bit for bit (as in sim_body)
-      FramePose fp;
-      fp.x = s.x;
-      fp.y = s.y;
-      fp.cth = have_trig ? s.cth : tc_cos(-s.theta);
-      fp.sth = have_trig ? -s.sth : tc_sin(-s.theta);
-      double pose[12];
-      cam_pose12(sa.a, live ? env : 0, fp, pose);
-      if (live && sub == 0) {
-        if (sa.ma.resident) {
-          // streamed call: the frame workgroup of this (step, env) may already be polling the row.  Each entry is one
-          // 8-byte device-scope store (sc1: written through to where every XCD sees it) and validates itself -- the
-          // reader waits until none of the twelve holds TC_POSE_EMPTY any more -- so the stores need no order among
-          // themselves and this wavefront waits for none of them.
-          unsigned long long* o = (unsigned long long*)(sa.ma.pose_rows + (row0 + env) * TC_POSE_ROW);
-#pragma unroll
-          for (int i = 0; i < 12; i++)
-            __hip_atomic_store(o + i, (unsigned long long)__double_as_longlong(pose[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-          double2* o = (double2*)(sa.ma.pose_rows + (row0 + env) * TC_POSE_ROW);
-#pragma unroll
-          for (int i = 0; i < 6; i++) o[i] = make_double2(pose[2 * i], pose[2 * i + 1]);
-        }
       }
     }
     TSTAMP(15);
