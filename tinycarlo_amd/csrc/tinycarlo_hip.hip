@@ -2517,7 +2517,8 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
     PathInfo pinfo;
     pinfo.ax = pinfo.ay = pinfo.bx = pinfo.by = pinfo.ori = 0;
     pinfo.valid = 0;
-    bool fresh = false;
+    bool fresh = false, track = false;
+    int track_man = 0;
     if ((flags & TC_F_AUTORESET) && nr) {
       const int cur = cursor;
       int node;
@@ -2549,18 +2550,13 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
       TSTAMP(25);
       d_car_kinematics(a.car, s, v, st, have_trig);
       TSTAMP(26);
-      if (fat_lds) {
-        trunc = d_find_local_path<TC_EL>(m, fl, s, man, status, pinfo, sub);
-      } else {
-        const FatGlobal fg = {m.lp_fat, m.lp_nodes};
-        trunc = d_find_local_path<TC_EL>(m, fg, s, man, status, pinfo, sub);
-      }
       have_trig = true;
+      track = true;
+      track_man = man;
     }
-    TSTAMP(27);
     // ---- this step's pose row, as early as the pose is final (nothing below moves the car): in a streamed call the frame
-    // workgroups of this (step, env) are waiting for it, and what follows -- distances, reward, rollout rows -- is more
-    // than half of the step
+    // workgroups of this (step, env) are waiting for it, and what follows -- lanepath tracking, distances, reward, rollout
+    // rows -- is most of the step
     if (sa.ma.pose_rows) {
       // car.py:159-165 takes cos(-theta), sin(-theta): tc_cos is exactly even and tc_sin exactly odd, so the values of
       // the front-axle update are reused bit for bit (as in sim_body)
@@ -2588,6 +2584,15 @@ __global__ __launch_bounds__(TC_ENVG_NT) void tc_envg_kernel(StepArgs sa_unused)
         }
       }
     }
+    if (track) {  // car.py:127-148 (the env went through the kinematic update above)
+      if (fat_lds) {
+        trunc = d_find_local_path<TC_EL>(m, fl, s, track_man, status, pinfo, sub);
+      } else {
+        const FatGlobal fg = {m.lp_fat, m.lp_nodes};
+        trunc = d_find_local_path<TC_EL>(m, fg, s, track_man, status, pinfo, sub);
+      }
+    }
+    TSTAMP(27);
     // ---- info (car.py:46-53), default reward / termination (env.py:93,99)
     const bool have_info = !fresh && s.lp_len >= 2;
     cte = 0;
