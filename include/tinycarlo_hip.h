@@ -285,7 +285,8 @@ int tc_step(tc_env* env, const void* car_control, int32_t control_dtype, const i
  * been called once before the first K-step call that renders (n_steps > 1 with an observation): tc_step_multi itself
  * never allocates and never waits for the device; without the scratch it returns TC_E_INVALID.
  * Env vars (all result-neutral, read at tc_env_create): TC_STREAM=0 chunked form; TC_STREAM_WAIT_US=t bound of a frame
- * workgroup's wait; TC_STREAM_TEST_SKIP=m (tests) frames with (step + env) % m == 0 are left to the recover kernel;
+ * workgroup's wait; TC_STREAM_SCRATCH_MB=m budget of the streamed form's scratch (default 16384: the rows of a segment
+ * are cut to fit, tc_env_reserve_steps); TC_STREAM_TEST_SKIP=m (tests) frames with (step + env) % m == 0 are left to the recover kernel;
  * TC_CHUNK=n steps per chunk (0: chunks follow each other on the caller's stream, no overlap, no streaming),
  * TC_ENV_GROUPED=0 one wavefront per env in every simulate launch (no overlap, no streaming),
  * TC_FIRST_CHUNK_PER_ENV=0, TC_FRAME_STREAMS=1 (chunked form), TC_ENVG_MAP_LDS=0, TC_MULTI_SPLIT=0 a single fused launch
@@ -315,7 +316,7 @@ int tc_step_multi(tc_env* env, const void* car_control, int32_t control_dtype, c
 
 /* Sizes the scratch of K-step calls that render observations, for calls of up to max_call_steps steps: per (step, env)
  * a pose row (128 B), a draw-list length and room for a draw list (20 B x lane-line edges of the map; only a frame's
- * overflow beyond the LDS-resident head travels through it).  Streamed form: min(max_call_steps, 128) steps x N envs
+ * overflow beyond the LDS-resident head travels through it).  Streamed form: min(max_call_steps, 128) steps x N envs, fewer when that would exceed TC_STREAM_SCRATCH_MB (16 GiB)
  * (cfg3: 22 MB per step); chunked form: a ring of TC_RING_SLOTS (3) chunks of min(max_call_steps, 16 or TC_CHUNK) steps.
  * A call of ANY n_steps then runs in segments / chunks that fit.  Re-allocating waits for the device first (an earlier
  * launch may still use the old arrays); a request the current scratch already covers returns at once.

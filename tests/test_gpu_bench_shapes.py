@@ -145,6 +145,7 @@ SWITCHES = [
     {},                                   # defaults: the 40-step call streamed -- one simulate launch, one gated frame launch
     {"TC_STREAM_TEST_SKIP": "3"},         # a third of the gated frame workgroups give up at once: the gate-2 pass draws them
     {"TC_STREAM_WAIT_US": "0"},           # no patience at all: whoever finds its row empty gives up and tells the others
+    {"TC_STREAM_SCRATCH_MB": "1"},        # scratch budget of 1 MB: rows of 256 envs x 5.4 KB -> 2-step segments, 20 per call
     {"TC_SEG_LDS": "0"},                  # draw lists through global memory only
     {"TC_SEG_LDS_CAP": "3"},              # every frame mixes an LDS head (3 segments) with a global tail
     {"TC_FRAME_ORDER": "0"},              # frame workgroups in env order instead of heaviest first

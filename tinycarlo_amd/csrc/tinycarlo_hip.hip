@@ -4362,6 +4362,16 @@ static bool fused_path(const tc_env* e, uint32_t flags) {
 // scratch of streamed calls: rows for min(max_call_steps, TC_STREAM_MAX_ROWS) steps
 static int reserve_stream(tc_env* e, int max_call_steps) {
   int rows = max_call_steps < TC_STREAM_MAX_ROWS ? max_call_steps : TC_STREAM_MAX_ROWS;
+  // the scratch of a row is N x (pose row + draw-list length + room for a whole draw list: 20 B x lane-line edges of the
+  // map -- knuffingen: 15 KB per frame); with many envs on a big map the rows are cut so that it stays within a budget
+  // (TC_STREAM_SCRATCH_MB, default 16 GiB), and a longer call runs as more, shorter segments
+  {
+    const double per_row = (double)e->k.N * ((double)e->k.seg_cap * 5 * sizeof(int) + sizeof(int) + TC_POSE_ROW * sizeof(double));
+    double budget = 16384.0 * 1048576.0;
+    if (const char* sb = getenv("TC_STREAM_SCRATCH_MB")) budget = atof(sb) * 1048576.0;
+    const double fit = budget / per_row;
+    if (fit < (double)rows) rows = (int)fit;
+  }
   if (rows < 2) rows = 2;
   if (e->st_rows >= rows) return TC_OK;
   HIP_TRY(hipDeviceSynchronize());  // earlier launches may still use the old arrays
