@@ -269,6 +269,37 @@ def test_first_step_multi_call_can_be_captured_into_a_graph():
     b.close()
 
 
+def test_two_handles_step_concurrently_on_two_streams():
+    """two env handles issue streamed calls at the same time on two streams: each one's frame launch fills the chip while
+    the other's simulate launch wants on (the gate kernel / the bounded waits / the recover pass are what keeps that from
+    hanging or from changing a result).  Same seeds and actions: the two rollouts must be identical, call after call."""
+    n, K = 4096, 24
+    a = make_env("simple_layout", "r64", "classes", n, autoreset=True)
+    b = make_env("simple_layout", "r64", "classes", n, autoreset=True)
+    a.reset(seed=21)
+    b.reset(seed=21)
+    ra, rb = a.alloc_rollout(K, keys="all"), b.alloc_rollout(K, keys="all")
+    a.reserve_steps(K)
+    b.reserve_steps(K)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for c in range(3):
+        cc, man = bench_actions(n, K, seed=40 + c)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            a.step_multi(cc, man, rollout=ra)
+        with torch.cuda.stream(s2):
+            b.step_multi(cc, man, rollout=rb)
+        torch.cuda.synchronize()
+        for k in ra:
+            x, y = ra[k], rb[k]
+            if x.dtype == torch.float64:
+                x, y = x.view(torch.int64), y.view(torch.int64)
+            assert torch.equal(x, y), (c, k)
+    a.close()
+    b.close()
+
+
 def test_prepared_call_is_step_multi_without_the_argument_checks():
     """prepare_step_multi(): the call object re-issues tc_step_multi on the same tensors (contents changed in between)"""
     n, K = 128, 12
